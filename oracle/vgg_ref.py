@@ -1,0 +1,76 @@
+"""ORACLE (test infrastructure, never imported by the product path).  PARITY UNPINNED.
+
+Torch-ops restatement of ``VGGPerceptualLoss`` (reference ``src/lib/loss.py:17-58``).  The
+reference takes its convolution stack from ``torchvision.models.vgg16(pretrained=True)
+.features[:23]`` (torchvision 0.4.0, ``environment.yml:297``) -- a third-party dependency that
+is absent from /root/reference and from this image, and whose weights need a download.  The
+layer layout below is torchvision's published VGG16 configuration "D":
+conv64,conv64,M,conv128,conv128,M,conv256x3,M,conv512x3 (all 3x3 pad 1 with bias, ReLU after
+each conv, 2x2/2 max-pool), sliced [0:4],[4:9],[9:16],[16:23] as at loss.py:28-31.  No
+reference run or fixture exists for it, so it is checked only against itself with synthetic
+weights.
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# (features index, cin, cout) of the ten convolutions inside features[:23]
+VGG16_CONVS = [(0, 3, 64), (2, 64, 64), (5, 64, 128), (7, 128, 128), (10, 128, 256),
+               (12, 256, 256), (14, 256, 256), (17, 256, 512), (19, 512, 512), (21, 512, 512)]
+# slices: ops are 'c<k>' (conv k of the list above, followed by ReLU) or 'p' (max-pool)
+VGG16_SLICES = [["c0", "c1"], ["p", "c2", "c3"], ["p", "c4", "c5", "c6"], ["p", "c7", "c8", "c9"]]
+IMAGENET_MEAN = (0.485, 0.456, 0.406)  # loss.py:37
+IMAGENET_STD = (0.229, 0.224, 0.225)   # loss.py:38
+
+
+def synth_vgg_weights(seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Synthetic He-normal weights under torchvision's key names (features.<idx>.weight/bias)."""
+    out = {}
+    for idx, cin, cout in VGG16_CONVS:
+        for leaf, shape in (("weight", (cout, cin, 3, 3)), ("bias", (cout,))):
+            key = f"features.{idx}.{leaf}"
+            rng = np.random.Generator(np.random.PCG64((zlib.crc32(key.encode()) + 7919 * seed) & 0xFFFFFFFF))
+            if leaf == "weight":
+                v = rng.normal(0.0, np.sqrt(2.0 / (cin * 9)), shape)
+            else:
+                v = rng.normal(0.0, 0.05, shape)
+            out[key] = torch.from_numpy(v.astype(np.float32))
+    return out
+
+
+def vgg_features(x: torch.Tensor, weights: Dict[str, torch.Tensor]):
+    """Returns the four slice outputs for a normalised NCHW batch."""
+    feats = []
+    for ops in VGG16_SLICES:
+        for op in ops:
+            if op == "p":
+                x = F.max_pool2d(x, 2, 2)
+            else:
+                idx = VGG16_CONVS[int(op[1:])][0]
+                x = F.relu(F.conv2d(x, weights[f"features.{idx}.weight"], weights[f"features.{idx}.bias"], padding=1))
+        feats.append(x)
+    return feats
+
+
+def vgg_perceptual_loss(inp: torch.Tensor, tgt: torch.Tensor, weights, resize: bool = True) -> torch.Tensor:
+    """loss.py:41-58: channel repeat for non-RGB, ImageNet normalise, optional bilinear
+    224x224 (align_corners=False), sum over slices of mean |x - y|."""
+    if inp.shape[1] != 3:
+        inp = inp.repeat(1, 3, 1, 1)
+        tgt = tgt.repeat(1, 3, 1, 1)
+    mean = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+    inp = (inp - mean) / std
+    tgt = (tgt - mean) / std
+    if resize:
+        inp = F.interpolate(inp, mode="bilinear", size=(224, 224), align_corners=False)
+        tgt = F.interpolate(tgt, mode="bilinear", size=(224, 224), align_corners=False)
+    loss = inp.new_zeros(())
+    for fx, fy in zip(vgg_features(inp, weights), vgg_features(tgt, weights)):
+        loss = loss + F.l1_loss(fx, fy)
+    return loss

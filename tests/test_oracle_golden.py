@@ -1,0 +1,147 @@
+"""CPU: the oracle (oracle/*.py) against the fixtures produced by running the reference
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hrnet_ref, pose_ref
+
+torch.set_num_threads(8)
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_state_dict_abi_w32(golden_dir):
+    """names + shapes of all 1754 entries equal the reference's."""
+    m = hrnet_ref.RefPoseNet("w32")
+    lines = [f"{k} {'x'.join(map(str, v.shape))}" for k, v in m.state_dict().items()]
+    with open(os.path.join(golden_dir, "g8_w32_keys.txt")) as f:
+        ref = f.read().splitlines()
+    assert len(lines) == 1754
+    assert lines == ref
+    assert sum(p.numel() for p in m.parameters()) == 28536113
+
+
+def test_state_dict_abi_w48(golden_dir):
+    g = _load(golden_dir, "g8_w48.npz")
+    m = hrnet_ref.load_synth(hrnet_ref.RefPoseNet("w48")).eval()
+    assert sum(p.numel() for p in m.parameters()) == int(g["nparams"]) == 63595745
+    crc = np.array([zlib.crc32((k + str(tuple(v.shape))).encode()) for k, v in m.state_dict().items()])
+    assert np.array_equal(crc, g["key_crc"])
+    from tests.golden.make_golden import synth_batch
+    img, _, _ = synth_batch(1, 128, 96, seed=5)
+    with torch.no_grad():
+        o = m(torch.from_numpy(img)).numpy()
+    np.testing.assert_allclose(o.reshape(-1)[::16], g["out_sample"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_tiny_forward_backward(golden_dir, mode):
+    g = _load(golden_dir, f"g1_tiny_{mode}.npz")
+    m = hrnet_ref.load_synth(hrnet_ref.RefPoseNet("tiny"))
+    m.train(mode == "train")
+    out = m(torch.from_numpy(g["img"]))
+    loss = pose_ref.person_mse_loss(out, torch.from_numpy(g["target"]), torch.from_numpy(g["target_weight"]))
+    loss.backward()
+    scale = np.abs(g["output"]).max()
+    assert np.abs(out.detach().numpy() - g["output"]).max() <= 1e-5 * scale
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    names = [k for k, _ in m.named_parameters()]
+    assert names == list(g["param_keys"])
+    norms = np.array([float(p.grad.double().norm()) for _, p in m.named_parameters()])
+    np.testing.assert_allclose(norms, g["gradnorm_all"], rtol=2e-4, atol=1e-7)
+    grads = dict(m.named_parameters())
+    nfull = 0
+    for k in g.files:
+        if k.startswith("grad/"):
+            ref = g[k]
+            got = grads[k[5:]].grad.numpy()
+            assert np.abs(got - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-6), k
+            nfull += 1
+    assert nfull > 30
+    bufs = dict(m.named_buffers())
+    bn = np.array([float(v.double().norm()) for _, v in m.named_buffers()])
+    np.testing.assert_allclose(bn, g["buffernorm_all"], rtol=1e-5)
+    for k in g.files:
+        if k.startswith("buf/"):
+            np.testing.assert_allclose(bufs[k[4:]].numpy(), g[k], rtol=1e-5, atol=1e-6)
+
+
+def test_w32_cfg1_argmax_and_stats(golden_dir):
+    """BASELINE cfg1: W32 256x192 bs 2 fwd + MSE + bwd on CPU; argmax bit-exact."""
+    from tests.golden.make_golden import synth_batch
+    g = _load(golden_dir, "g3_w32_256x192.npz")
+    m = hrnet_ref.load_synth(hrnet_ref.RefPoseNet("w32")).train()
+    img, tgt, tw = synth_batch(2, 256, 192, seed=1234, sigma=2.0)
+    out = m(torch.from_numpy(img))
+    loss = pose_ref.person_mse_loss(out, torch.from_numpy(tgt), torch.from_numpy(tw))
+    loss.backward()
+    o = out.detach().numpy()
+    p, mv = pose_ref.get_max_preds(o)
+    assert np.array_equal(p, g["argmax_xy"])
+    np.testing.assert_allclose(mv, g["maxvals"], rtol=1e-4)
+    np.testing.assert_allclose(o.reshape(-1)[::64], g["out_sample"], rtol=0, atol=1e-4 * float(g["out_absmax"]))
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    gn = {}
+    for k, prm in m.named_parameters():
+        top = k.split(".")[0]
+        gn[top] = gn.get(top, 0.0) + float((prm.grad.double() ** 2).sum())
+    vals = np.array([np.sqrt(gn[k]) for k in g["gradnorm_keys"]])
+    np.testing.assert_allclose(vals, g["gradnorm_vals"], rtol=1e-3)
+    np.testing.assert_allclose(m.bn1.running_mean.numpy(), g["rm_bn1"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(m.stage4[2].branches[0][3].bn2.running_var.numpy(), g["rv_last"], rtol=1e-4)
+
+
+def test_w32_flip_test_eval(golden_dir):
+    from tests.golden.make_golden import synth_batch
+    g = _load(golden_dir, "g3_w32_256x192.npz")
+    m = hrnet_ref.load_synth(hrnet_ref.RefPoseNet("w32")).eval()
+    img, _, _ = synth_batch(2, 256, 192, seed=1234, sigma=2.0)
+    with torch.no_grad():
+        of = pose_ref.forward_pass(m, torch.from_numpy(img), flip=True).numpy()
+    p, mv = pose_ref.get_max_preds(of)
+    assert np.array_equal(p, g["flip_argmax_xy"])
+    np.testing.assert_allclose(of.reshape(-1)[::64], g["flip_sample"], rtol=0, atol=2e-4 * np.abs(g["flip_sample"]).max())
+
+
+def test_mse_loss_golden(golden_dir):
+    g = _load(golden_dir, "g6_mse.npz")
+    for name in ("b4", "b1"):
+        o = torch.from_numpy(g[f"{name}_o"]).requires_grad_(True)
+        l = pose_ref.person_mse_loss(o, torch.from_numpy(g[f"{name}_t"]), torch.from_numpy(g[f"{name}_w"]))
+        l.backward()
+        assert abs(l.item() - float(g[f"{name}_loss"])) < 1e-6 * abs(float(g[f"{name}_loss"]))
+        np.testing.assert_allclose(o.grad.numpy(), g[f"{name}_grad"], rtol=1e-5, atol=1e-9)
+        # closed form used by the HIP kernel
+        w = torch.from_numpy(g[f"{name}_w"])[..., None]
+        closed = 0.5 * (((o.detach() - torch.from_numpy(g[f"{name}_t"])) * w) ** 2).mean()
+        assert abs(closed.item() - l.item()) < 1e-6 * abs(l.item())
+
+
+def test_decode_golden(golden_dir):
+    g = _load(golden_dir, "g7_decode.npz")
+    p, mv = pose_ref.get_max_preds(g["hm"])
+    assert np.array_equal(p, g["preds"]) and np.array_equal(mv, g["maxvals"])
+    fp, fmv, coords = pose_ref.final_preds(g["hm"], g["center"], g["scale"])
+    assert np.array_equal(coords, g["final_coords"])
+    np.testing.assert_allclose(fp, g["final_preds"], rtol=1e-5, atol=1e-4)
+    assert np.array_equal(pose_ref.flip_back(g["hm"]), g["flip_back"])
+    kp = g["nms_kpts"].reshape(6, -1)
+    for t, key in ((0.9, "keep_09"), (0.5, "keep_05")):
+        assert pose_ref.oks_nms(kp, g["nms_scores"], g["nms_areas"], t) == list(g[key])
+
+
+def test_pck_self_consistency():
+    """accuracy is unpinned (corrupted reference line); sanity: perfect prediction -> 1.0."""
+    rng = np.random.default_rng(0)
+    t = np.zeros((2, 17, 24, 16), np.float32)
+    for n in range(2):
+        for j in range(17):
+            t[n, j, rng.integers(2, 24), rng.integers(2, 16)] = 1.0
+    acc, avg, cnt, _ = pose_ref.pck_accuracy(t.copy(), t)
+    assert avg == 1.0 and cnt == 17
