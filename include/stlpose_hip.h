@@ -1,0 +1,222 @@
+/*
+ * stlpose_hip.h -- C ABI of libstlpose_hip.so (gfx950 / MI355X).
+ *
+ * The reference (angelvillar96/STLPose) has no FFI: its hot path is ATen/cuDNN ops invoked
+ * from Python nn.Modules.  This header is the boundary the build creates for that path
+ * (SURVEY.md 8(b) "What the native side must export").  Every entry point names the reference
+ * computation it replaces.  Conventions:
+ *   - plain pointers + sizes only; all tensor pointers are DEVICE pointers owned by the caller
+ *     (the Python host allocates them with torch); kernels never allocate;
+ *   - activations are NHWC ("channels last"), element type `dtype` = STL_F32 | STL_BF16,
+ *     accumulation always fp32, BatchNorm statistics fp64;
+ *   - every call enqueues on `stream` (a hipStream_t passed as void*) and returns without
+ *     synchronising, so a whole step can be captured in a hipGraph;
+ *   - return value 0 = ok, negative = error (message via stl_last_error()); the Python mirror
+ *     raises RuntimeError like the reference's ATen calls would.
+ */
+#ifndef STLPOSE_HIP_H
+#define STLPOSE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STL_F32 0
+#define STL_BF16 1
+#define STL_NSHARD 8 /* BatchNorm sum buffers are [STL_NSHARD][2*C] doubles (atomic de-contention) */
+
+/* How a tensor is read ("normalise on load"): a conv / sum kernel applies the producing
+ * BatchNorm (+ReLU) while staging its input, so BN never costs its own pass over HBM. */
+#define STL_SRC_PLAIN 0 /* v = x                                              */
+#define STL_SRC_BN 1    /* v = [relu](a*x + b), a,b from batch or running stats  */
+#define STL_SRC_BNBWD 2 /* v = a*(dt - r1/n - yhat*r2/n): BatchNorm backward on load */
+
+typedef struct stl_src {
+    const void* x;        /* PLAIN/BN: tensor; BNBWD: dt (grad wrt BN output, post ReLU mask) */
+    const void* y;        /* BNBWD: raw conv output the BN normalised                     */
+    int32_t mode;         /* STL_SRC_*                                                    */
+    int32_t relu;         /* BN: apply ReLU after the affine                              */
+    const double* stats;  /* [NSHARD][2C] batch sum / sum-of-squares (train) or NULL (eval) */
+    const double* rstats; /* BNBWD: [NSHARD][2C] r1 = sum dt, r2 = sum dt*yhat             */
+    const float* gamma;   /* [C]                                                          */
+    const float* beta;    /* [C]                                                          */
+    const float* rmean;   /* [C] running mean (eval)                                      */
+    const float* rvar;    /* [C] running var  (eval)                                      */
+    float inv_count;      /* 1 / (B*H*W) of the normalised tensor                         */
+    float eps;
+} stl_src;
+
+/* Implicit-GEMM convolution (no im2col), 3x3 pad 1 or 1x1 pad 0, MFMA 16x16 tiles.
+ * Replaces nn.Conv2d forward (reference src/models/HRnet.py:26-29,69-75,146-150,201-205,
+ * 219-223,290-294,352-356,371-373) and, with `transposed` weights, aten::convolution_backward's
+ * data gradient.  out[b,oy,ox,co] = sum_{ky,kx,ci} src(b, oy*stride+ky-pad, ox*stride+kx-pad, ci)
+ * * w[co][ky*ks+kx][ci].   stuff=1: the source is a stride-2 zero-stuffed view of a half-size
+ * tensor (data gradient of a stride-2 conv).  Epilogue (all optional): +bias, +addend, ReLU
+ * mask from the BatchNorm that produced this conv's input in the forward pass (mask_*),
+ * ReLU, per-channel sum/sumsq of the stored output (out_stats) or r1/r2 against mask_y (red). */
+typedef struct stl_conv {
+    int32_t dtype;
+    int32_t B, Hi, Wi, Ci; /* source tensor dims (for stuff=1: the half-size tensor) */
+    int32_t Ho, Wo, Co;    /* output dims                                          */
+    int32_t ks, stride, stuff;
+    int32_t TH, TW;        /* output tile (rows x cols), TH*TW <= 128              */
+    stl_src src;
+    const void* w;         /* [Co][ks*ks][Ci] dtype                               */
+    void* out;             /* [B,Ho,Wo,Co] dtype                                  */
+    const float* bias;     /* [Co] or NULL                                        */
+    int32_t out_relu;
+    double* out_stats;     /* [NSHARD][2*Co] += or NULL                           */
+    const void* addend;    /* [B,Ho,Wo,Co] dtype or NULL                          */
+    const void* mask_y;    /* [B,Ho,Wo,Co] raw tensor whose BN(+ReLU) gates `out`  */
+    stl_src mask_bn;       /* BN parameters for mask_y (mode must be STL_SRC_BN)   */
+    double* red;           /* [NSHARD][2*Co] += (r1,r2) against mask_y or NULL     */
+} stl_conv;
+int stl_conv_forward(const stl_conv* p, void* stream);
+
+/* Weight gradient of the same convolution (aten::convolution_backward, weight part).
+ * partial[s][co][tap][ci] (fp32) for s < nsplit; summed later by stl_reduce_slabs.
+ * h = the conv's forward input (PLAIN or BN source), g = gradient of its output (PLAIN or BNBWD). */
+typedef struct stl_wgrad {
+    int32_t dtype;
+    int32_t B, Hi, Wi, Ci, Ho, Wo, Co, ks, stride;
+    int32_t TH, TW, nsplit;
+    stl_src h;
+    stl_src g;
+    float* partial; /* [nsplit][Co][ks*ks][Ci] */
+} stl_wgrad;
+int stl_conv_wgrad(const stl_wgrad* p, void* stream);
+
+/* Sum of up to 4 terms + optional ReLU, each term read through an stl_src and optionally
+ * nearest-upsampled by 2^shift.  Replaces the residual add+ReLU of the reference's blocks
+ * (HRnet.py:58-59,99-100), the materialisation of transition outputs (:352-358,371-376) and the
+ * multi-resolution exchange sum  out_i = ReLU(sum_j f_ij(x_j))  incl. nn.Upsample (:207,:255-264). */
+typedef struct stl_term {
+    stl_src src;
+    int32_t shift; /* source is (H>>shift, W>>shift) */
+} stl_term;
+typedef struct stl_fuse {
+    int32_t dtype, B, H, W, C, nterms, relu;
+    stl_term t[4];
+    void* out;
+} stl_fuse;
+int stl_fuse_forward(const stl_fuse* p, void* stream);
+
+/* Backward of stl_fuse_forward: du = (sum_k dz_k) * (z > 0); for every same-resolution BN term
+ * accumulates r1 = sum du, r2 = sum du*yhat into that term's rstats.  (aten::threshold_backward
+ * + native_batch_norm_backward reductions.) */
+typedef struct stl_fuse_bwd {
+    int32_t dtype, B, H, W, C, ngrads, relu, nbn;
+    const void* dz[4];
+    const void* z;
+    void* du;
+    stl_src bn[4];    /* same-res BN terms (mode STL_SRC_BN): x = raw y, stats, gamma */
+    double* rstats[4];
+} stl_fuse_bwd;
+int stl_fuse_backward(const stl_fuse_bwd* p, void* stream);
+
+/* Backward of one nearest-upsampled BN term (upsample_nearest2d_backward + BN reductions):
+ * dt[b,y,x,c] = sum over the 2^shift x 2^shift patch of du; r1/r2 against the low-res raw y. */
+typedef struct stl_upbwd {
+    int32_t dtype, B, H, W, C, shift; /* H,W = LOW-res dims */
+    const void* du;                   /* [B, H<<shift, W<<shift, C] */
+    void* dt;                         /* [B,H,W,C] */
+    stl_src bn;
+    double* rstats;
+} stl_upbwd;
+int stl_upsample_backward(const stl_upbwd* p, void* stream);
+
+/* 3x3 patches of an NCHW fp32 image batch (3 channels) as a 32-wide NHWC tensor
+ * (k = (ky*3+kx)*3 + c, zero for k >= 27 and outside the image), optionally ImageNet-normalised
+ * first ((x-mean)/std, reference lib/loss.py:46-47).  Turns the 3-channel stem conv
+ * (HRnet.py:290) / VGG conv1_1 into a 1x1 convolution with Ci=32. */
+int stl_patch3x3(int dtype, const float* img, void* out, int B, int H, int W, int stride,
+                 const float* mean3, const float* std3, void* stream);
+
+/* 1x1 head with bias: NHWC dtype [B,H,W,Ci] -> NCHW fp32 [B,J,H,W]  (HRnet.py:331-337,466). */
+int stl_head_forward(int dtype, const void* x, const float* w, const float* bias, float* out,
+                     int B, int H, int W, int Ci, int J, void* stream);
+/* its backward: dx (dtype NHWC), per-block partials of dw [J][Ci] and db [J] (fp32). */
+int stl_head_backward(int dtype, const void* x, const float* w, const float* dout, void* dx,
+                      float* partial, int nblk, int B, int H, int W, int Ci, int J, void* stream);
+
+/* PersonMSELoss forward+backward (reference lib/loss.py:71-94):
+ * loss = 0.5*mean(((o-t)*w)^2) over all B*J*H*W;  dout = (o-t)*w^2 / (B*J*H*W) * gscale. */
+int stl_mse_loss(const float* out, const float* target, const float* tweight, float* dout,
+                 double* partial, int nblk, float* loss, int B, int J, int HW, float gscale, void* stream);
+
+/* get_max_preds_hrnet (reference lib/pose_parsing.py:16-55): first-max flat argmax + max per
+ * (b,joint); idx int32 [B*J], maxval f32 [B*J], preds f32 [B*J*2] (x,y, zeroed when max<=0). */
+int stl_heatmap_argmax(const float* hm, int32_t* idx, float* maxval, float* preds, int BJ, int H,
+                       int W, void* stream);
+/* flip_back + 1px shift + average of forward_pass(flip=True) (lib/inference.py:20-26,
+ * lib/transforms.py:147-164) on device: out = 0.5*(a + shift(flip(b))). */
+int stl_flip_merge(const float* a, const float* bflip, float* out, const int32_t* perm, int B, int J,
+                   int H, int W, void* stream);
+/* +-0.25 px refinement + inverse affine of get_final_preds_hrnet (lib/pose_parsing.py:58-92). */
+int stl_final_preds(const float* hm, const float* center, const float* scale, float* preds,
+                    float* maxval, int B, int J, int H, int W, void* stream);
+
+/* Table-driven batched helpers (one launch for the whole network). */
+typedef struct stl_wprep { /* one conv weight: OIHW fp32 master -> kernel layouts */
+    int64_t src_off;  /* element offset in master */
+    int64_t fwd_off;  /* element offset in `wk`: [Co][tap][Cip] (Cip = padded Ci)          */
+    int64_t bwd_off;  /* element offset in `wk`: [Ci][8-tap][Co] for the data gradient, or -1 */
+    int32_t Co, Ci, ks, Cip; /* Cip: Ci padded (stem patches: 27 -> 32)                     */
+    int32_t patch;    /* 1: Ci*ks*ks flattened as k=(tap*Ci + ci) into Cip (stem / VGG conv1_1) */
+    int32_t blk0;     /* first block of this entry */
+} stl_wprep;
+int stl_weight_prep(int dtype, const float* master, void* wk, const stl_wprep* tab, int n,
+                    int nblocks, void* stream);
+
+typedef struct stl_slab { /* one wgrad result: sum partial[s] -> grad (OIHW fp32) */
+    int64_t part_off; /* element offset into `partials` */
+    int64_t grad_off; /* element offset into `grads`    */
+    int32_t nsplit, Co, Ci, ks, Cip, patch, blk0;
+    int32_t pad; /* if non-zero: element stride between consecutive splits (default Co*taps*Ci) */
+} stl_slab;
+int stl_reduce_slabs(const float* partials, float* grads, const stl_slab* tab, int n, int nblocks,
+                     void* stream);
+
+typedef struct stl_bnrec { /* one BatchNorm layer */
+    int64_t stats_off;  /* offset (doubles) of its [NSHARD][2C] block in the stats arena  */
+    int64_t param_off;  /* offset of gamma in the fp32 master (beta follows at +C)        */
+    int64_t buf_off;    /* offset of running_mean in the buffer arena (running_var at +C) */
+    int32_t C;
+    float inv_count;
+} stl_bnrec;
+/* running_mean/var momentum update (unbiased var), reference nn.BatchNorm2d(momentum=0.1). */
+int stl_bn_running_update(const double* stats, float* buffers, int64_t* num_batches_tracked /* [n] or NULL */,
+                          const stl_bnrec* tab, int n, float momentum, void* stream);
+/* dgamma = r2, dbeta = r1 from the backward reduction arena into the flat grad buffer. */
+int stl_bn_param_grads(const double* rstats, float* grads, const stl_bnrec* tab, int n, void* stream);
+
+/* Optimisers over the flat fp32 master (torch.optim.Adam / SGD semantics, reference
+ * lib/model_setup.py:135-141).  hyper = device float[8]: lr, beta1, beta2, eps, weight_decay,
+ * momentum, nesterov, gscale;  step = device int32 (incremented by the kernel). */
+int stl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                  int32_t* step, void* stream);
+int stl_sgd_step(float* p, const float* g, float* mom, int64_t n, const float* hyper, int32_t* step,
+                 void* stream);
+
+/* VGG perceptual path (reference lib/loss.py:17-58). */
+int stl_maxpool2x2(int dtype, const void* x, void* out, int B, int H, int W, int C, void* stream);
+int stl_l1_partial(int dtype, const void* a, const void* b, int64_t n, double* partial, int nblk,
+                   void* stream); /* partial[i] = sum |a-b| over block i's share */
+int stl_bilinear_nchw(const float* in, float* out, int B, int C, int H, int W, int Ho, int Wo,
+                      void* stream); /* F.interpolate(mode='bilinear', align_corners=False) */
+int stl_sum_partials(const double* partial, int n, double scale, float* out, int accumulate, void* stream);
+
+/* Layout / dtype utilities. */
+int stl_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H, int W, void* stream);
+int stl_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H, int W, void* stream);
+
+/* Self-checks that need no reference: MFMA / LDS-transpose lane maps (used by tests). */
+int stl_selftest_mfma(float* out /* [4] max abs err: bf16 mfma, f32 mfma, tr-read, f64 atomic */, void* stream);
+
+const char* stl_last_error(void);
+int stl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

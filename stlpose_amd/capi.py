@@ -1,0 +1,129 @@
+"""ctypes binding of libstlpose_hip.so (see include/stlpose_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing this module raises at
+import-of-symbols time (``lib()``), loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstlpose_hip.so")
+
+F32, BF16 = 0, 1
+NSHARD = 8
+SRC_PLAIN, SRC_BN, SRC_BNBWD = 0, 1, 2
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class Src(C.Structure):
+    _fields_ = [("x", vp), ("y", vp), ("mode", i32), ("relu", i32), ("stats", vp), ("rstats", vp),
+                ("gamma", vp), ("beta", vp), ("rmean", vp), ("rvar", vp), ("inv_count", f32), ("eps", f32)]
+
+
+class Conv(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("Hi", i32), ("Wi", i32), ("Ci", i32), ("Ho", i32), ("Wo", i32),
+                ("Co", i32), ("ks", i32), ("stride", i32), ("stuff", i32), ("TH", i32), ("TW", i32),
+                ("src", Src), ("w", vp), ("out", vp), ("bias", vp), ("out_relu", i32), ("out_stats", vp),
+                ("addend", vp), ("mask_y", vp), ("mask_bn", Src), ("red", vp)]
+
+
+class Wgrad(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("Hi", i32), ("Wi", i32), ("Ci", i32), ("Ho", i32), ("Wo", i32),
+                ("Co", i32), ("ks", i32), ("stride", i32), ("TH", i32), ("TW", i32), ("nsplit", i32),
+                ("h", Src), ("g", Src), ("partial", vp)]
+
+
+class Term(C.Structure):
+    _fields_ = [("src", Src), ("shift", i32)]
+
+
+class Fuse(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("nterms", i32), ("relu", i32),
+                ("t", Term * 4), ("out", vp)]
+
+
+class FuseBwd(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("ngrads", i32), ("relu", i32),
+                ("nbn", i32), ("dz", vp * 4), ("z", vp), ("du", vp), ("bn", Src * 4), ("rstats", vp * 4)]
+
+
+class UpBwd(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("shift", i32),
+                ("du", vp), ("dt", vp), ("bn", Src), ("rstats", vp)]
+
+
+class WPrep(C.Structure):
+    _fields_ = [("src_off", i64), ("fwd_off", i64), ("bwd_off", i64), ("Co", i32), ("Ci", i32), ("ks", i32),
+                ("Cip", i32), ("patch", i32), ("blk0", i32)]
+
+
+class Slab(C.Structure):
+    _fields_ = [("part_off", i64), ("grad_off", i64), ("nsplit", i32), ("Co", i32), ("Ci", i32), ("ks", i32),
+                ("Cip", i32), ("patch", i32), ("blk0", i32), ("pad", i32)]
+
+
+class BNRec(C.Structure):
+    _fields_ = [("stats_off", i64), ("param_off", i64), ("buf_off", i64), ("C", i32), ("inv_count", f32)]
+
+
+# name -> argtypes (restype is always int unless noted); every symbol include/stlpose_hip.h declares
+SIGNATURES = {
+    "stl_conv_forward": [C.POINTER(Conv), vp],
+    "stl_conv_wgrad": [C.POINTER(Wgrad), vp],
+    "stl_fuse_forward": [C.POINTER(Fuse), vp],
+    "stl_fuse_backward": [C.POINTER(FuseBwd), vp],
+    "stl_upsample_backward": [C.POINTER(UpBwd), vp],
+    "stl_patch3x3": [i32, vp, vp, i32, i32, i32, i32, vp, vp, vp],
+    "stl_head_forward": [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "stl_head_backward": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "stl_mse_loss": [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, f32, vp],
+    "stl_heatmap_argmax": [vp, vp, vp, vp, i32, i32, i32, vp],
+    "stl_flip_merge": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "stl_final_preds": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "stl_weight_prep": [i32, vp, vp, vp, i32, i32, vp],
+    "stl_reduce_slabs": [vp, vp, vp, i32, i32, vp],
+    "stl_bn_running_update": [vp, vp, vp, vp, i32, f32, vp],
+    "stl_bn_param_grads": [vp, vp, vp, i32, vp],
+    "stl_adam_step": [vp, vp, vp, vp, i64, vp, vp, vp],
+    "stl_sgd_step": [vp, vp, vp, i64, vp, vp, vp],
+    "stl_maxpool2x2": [i32, vp, vp, i32, i32, i32, i32, vp],
+    "stl_l1_partial": [i32, vp, vp, i64, vp, i32, vp],
+    "stl_bilinear_nchw": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "stl_sum_partials": [vp, i32, C.c_double, vp, i32, vp],
+    "stl_nchw_to_nhwc": [i32, vp, vp, i32, i32, i32, i32, vp],
+    "stl_nhwc_to_nchw": [i32, vp, vp, i32, i32, i32, i32, vp],
+    "stl_selftest_mfma": [vp, vp],
+    "stl_version": [],
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m stlpose_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+        l = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the ABI and this table disagree
+            fn.argtypes = args
+            fn.restype = C.c_int
+        l.stl_last_error.argtypes = []
+        l.stl_last_error.restype = C.c_char_p
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise RuntimeError(f"stlpose_hip {what}: {lib().stl_last_error().decode()}")
+
+
+def call(name: str, *args) -> None:
+    check(getattr(lib(), name)(*args), name)

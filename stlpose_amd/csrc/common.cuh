@@ -1,0 +1,171 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA 16x16 tiles).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/stlpose_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct alignas(16) V16 {
+    uint32_t w[4];
+};
+
+int stl_set_error(const char* fmt, ...);
+#define STL_CHECK(cond, ...)                 \
+    do {                                     \
+        if (!(cond)) return stl_set_error(__VA_ARGS__); \
+    } while (0)
+#define STL_LAUNCH_CHECK(name)                                                       \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) return stl_set_error("%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------- element traits
+template <typename T>
+struct ET;
+template <>
+struct ET<float> {
+    static constexpr int KV = 4;   // elements per 16 bytes
+    static constexpr int CK = 16;  // channels per 64-byte K chunk
+};
+template <>
+struct ET<__bf16> {
+    static constexpr int KV = 8;
+    static constexpr int CK = 32;
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16(float f) {
+    __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+    return (uint32_t)__builtin_bit_cast(unsigned short, h);
+}
+
+template <typename T>
+__device__ __forceinline__ void unpack(const V16& v, float* f);
+template <>
+__device__ __forceinline__ void unpack<float>(const V16& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(v.w[i]);
+}
+template <>
+__device__ __forceinline__ void unpack<__bf16>(const V16& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(v.w[i] << 16);
+        f[2 * i + 1] = __uint_as_float(v.w[i] & 0xFFFF0000u);
+    }
+}
+template <typename T>
+__device__ __forceinline__ V16 pack(const float* f);
+template <>
+__device__ __forceinline__ V16 pack<float>(const float* f) {
+    V16 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v.w[i] = __float_as_uint(f[i]);
+    return v;
+}
+template <>
+__device__ __forceinline__ V16 pack<__bf16>(const float* f) {
+    V16 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v.w[i] = f32_to_bf16(f[2 * i]) | (f32_to_bf16(f[2 * i + 1]) << 16);
+    return v;
+}
+// value as stored (rounded to T) -- so statistics see exactly what consumers will read
+template <typename T>
+__device__ __forceinline__ float round_to(float f);
+template <>
+__device__ __forceinline__ float round_to<float>(float f) { return f; }
+template <>
+__device__ __forceinline__ float round_to<__bf16>(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+
+__device__ __forceinline__ V16 zero16() {
+    V16 v;
+    v.w[0] = v.w[1] = v.w[2] = v.w[3] = 0u;
+    return v;
+}
+__device__ __forceinline__ V16 ldg16(const void* p) { return *reinterpret_cast<const V16*>(p); }
+__device__ __forceinline__ void stg16(void* p, const V16& v) { *reinterpret_cast<V16*>(p) = v; }
+
+// ---------------------------------------------------------------- MFMA 16x16 step over one 64-byte K slice
+// A fragment: lane (row = lane&15, g = lane>>4) holds the KV consecutive K elements g*KV..g*KV+KV-1
+// B fragment: lane (col = lane&15, g) holds the same K elements.  C/D: col = lane&15, row = 4*g + reg.
+template <typename T>
+__device__ __forceinline__ void mma16(f32x4& acc, const V16& a, const V16& b);
+template <>
+__device__ __forceinline__ void mma16<__bf16>(f32x4& acc, const V16& a, const V16& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma16<float>(f32x4& acc, const V16& a, const V16& b) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w[s]), __uint_as_float(b.w[s]), acc, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------- per-channel constants of an stl_src
+// ca/cb/cc: v = ca*x + cb (BN) or v = ca*dt + cb*y + cc (BNBWD).  mu/rs: mean and 1/std (for yhat).
+__device__ __forceinline__ void bn_mean_rstd(const stl_src& s, int c, int C, float& mean, float& rstd) {
+    if (s.stats) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < STL_NSHARD; ++k) {
+            s0 += s.stats[(size_t)k * 2 * C + c];
+            s1 += s.stats[(size_t)k * 2 * C + C + c];
+        }
+        double m = s0 * (double)s.inv_count;
+        double var = s1 * (double)s.inv_count - m * m;
+        if (var < 0.0) var = 0.0;
+        mean = (float)m;
+        rstd = (float)(1.0 / sqrt(var + (double)s.eps));
+    } else {
+        mean = s.rmean[c];
+        rstd = (float)(1.0 / sqrt((double)s.rvar[c] + (double)s.eps));
+    }
+}
+
+__device__ __forceinline__ void src_consts(const stl_src& s, int c, int C, float& ca, float& cb, float& cc) {
+    if (s.mode == STL_SRC_PLAIN) {
+        ca = 1.f, cb = 0.f, cc = 0.f;
+        return;
+    }
+    float mean, rstd;
+    bn_mean_rstd(s, c, C, mean, rstd);
+    const float g = s.gamma[c];
+    if (s.mode == STL_SRC_BN) {
+        ca = g * rstd;
+        cb = s.beta[c] - mean * ca;
+        cc = 0.f;
+    } else {  // BNBWD
+        double r1 = 0.0, r2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < STL_NSHARD; ++k) {
+            r1 += s.rstats[(size_t)k * 2 * C + c];
+            r2 += s.rstats[(size_t)k * 2 * C + C + c];
+        }
+        const float c1 = (float)(r1 * (double)s.inv_count);
+        const float c2 = (float)(r2 * (double)s.inv_count);
+        const float al = g * rstd;
+        ca = al;
+        cb = -al * rstd * c2;
+        cc = al * (mean * rstd * c2 - c1);
+    }
+}
+
+// block-wide helpers ---------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

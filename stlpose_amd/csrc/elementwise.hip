@@ -1,0 +1,999 @@
+// HBM-bound kernels of the HRNet step on gfx950: multi-term sum (+upsample, +BN on load, +ReLU),
+// its backward reductions, stem patches, heatmap head, masked MSE, heatmap decode.
+// All activation traffic is 16-byte vectors along the NHWC channel axis.
+#include "common.cuh"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ void load8(const void* base, size_t elem, float* f) {
+    if constexpr (sizeof(T) == 2) {
+        unpack<__bf16>(ldg16((const char*)base + elem * 2), f);
+    } else {
+        unpack<float>(ldg16((const char*)base + elem * 4), f);
+        unpack<float>(ldg16((const char*)base + elem * 4 + 16), f + 4);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store8(void* base, size_t elem, const float* f) {
+    if constexpr (sizeof(T) == 2) {
+        stg16((char*)base + elem * 2, pack<__bf16>(f));
+    } else {
+        stg16((char*)base + elem * 4, pack<float>(f));
+        stg16((char*)base + elem * 4 + 16, pack<float>(f + 4));
+    }
+}
+
+// Block-level flush of per-thread channel-group sums: thread t holds NS sets of 8 channel sums for
+// channel group (t % VPC).  Deterministic tree in LDS, then fp64 atomics into shard (block & 7).
+template <int NS>
+__device__ __forceinline__ void flush_sets(float (*acc)[8], float* red, int C, int VPC, double* const* dst,
+                                           const int* which, int nsets) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[(tid * NS + s) * 8 + j] = acc[s][j];
+    __syncthreads();
+    for (int e = tid; e < nsets * C; e += nthr) {
+        const int s = e / C, c = e - s * C, cg = c >> 3, j = c & 7;
+        float sum = 0.f;
+        for (int q = cg; q < nthr; q += VPC) sum += red[(q * NS + s) * 8 + j];
+        atomicAdd(dst[s] + (size_t)(blockIdx.x & (STL_NSHARD - 1)) * 2 * C + which[s] * C + c, (double)sum);
+    }
+}
+
+// ---------------------------------------------------------------- fuse forward
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_fwd_kernel(const stl_fuse p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* cs = reinterpret_cast<float*>(smem);  // [nterms][2][C]
+    const int C = p.C, VPC = C >> 3;
+    for (int e = threadIdx.x; e < p.nterms * C; e += blockDim.x) {
+        const int t = e / C, c = e - t * C;
+        float a, b, cc;
+        src_consts(p.t[t].src, c, C, a, b, cc);
+        cs[(t * 2) * C + c] = a, cs[(t * 2 + 1) * C + c] = b;
+    }
+    __syncthreads();
+    const size_t total = (size_t)p.B * p.H * p.W * VPC;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (size_t)gridDim.x * blockDim.x) {
+        const size_t pi = v / VPC;
+        const int cg = (int)(v - pi * VPC), c0 = cg * 8;
+        const int x = (int)(pi % p.W);
+        const size_t by = pi / p.W;
+        const int y = (int)(by % p.H), b = (int)(by / p.H);
+        float s[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = 0.f;
+        for (int t = 0; t < p.nterms; ++t) {
+            const stl_term& tm = p.t[t];
+            const int hs = p.H >> tm.shift, ws = p.W >> tm.shift;
+            const size_t off = (((size_t)b * hs + (y >> tm.shift)) * ws + (x >> tm.shift)) * C + c0;
+            float f[8];
+            load8<T>(tm.src.x, off, f);
+            if (tm.src.mode == STL_SRC_BN) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float u = cs[(t * 2) * C + c0 + j] * f[j] + cs[(t * 2 + 1) * C + c0 + j];
+                    // BN terms are rounded to the storage type like a materialised BN output would be
+                    f[j] = tm.src.relu ? fmaxf(u, 0.f) : u;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += f[j];
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] = fmaxf(s[j], 0.f);
+        }
+        store8<T>(p.out, pi * C + c0, s);
+    }
+}
+
+// ---------------------------------------------------------------- fuse backward
+template <typename T>
+__global__ void fuse_bwd_kernel(const stl_fuse_bwd p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int C = p.C, VPC = C >> 3;
+    float* mu = reinterpret_cast<float*>(smem);  // [nbn][2][C] mean, rstd
+    float* red = mu + (size_t)(p.nbn > 0 ? p.nbn : 1) * 2 * C;
+    for (int e = threadIdx.x; e < p.nbn * C; e += blockDim.x) {
+        const int t = e / C, c = e - t * C;
+        float m, r;
+        bn_mean_rstd(p.bn[t], c, C, m, r);
+        mu[(t * 2) * C + c] = m, mu[(t * 2 + 1) * C + c] = r;
+    }
+    __syncthreads();
+    float acc[5][8];
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[s][j] = 0.f;
+    const size_t total = (size_t)p.B * p.H * p.W * VPC;
+    const int cg = threadIdx.x % VPC, c0 = cg * 8;  // (gridDim*blockDim) % VPC == 0 by construction
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (size_t)gridDim.x * blockDim.x) {
+        const size_t off = v * 8;
+        float d[8];
+        load8<T>(p.dz[0], off, d);
+        for (int k = 1; k < p.ngrads; ++k) {
+            float e[8];
+            load8<T>(p.dz[k], off, e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] += e[j];
+        }
+        if (p.relu) {
+            float z[8];
+            load8<T>(p.z, off, z);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = z[j] > 0.f ? d[j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = round_to<T>(d[j]);
+        store8<T>(p.du, off, d);
+        if (p.nbn > 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[0][j] += d[j];
+            for (int t = 0; t < p.nbn; ++t) {
+                float y[8];
+                load8<T>(p.bn[t].x, off, y);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    acc[1 + t][j] += d[j] * (y[j] - mu[(t * 2) * C + c0 + j]) * mu[(t * 2 + 1) * C + c0 + j];
+            }
+        }
+    }
+    if (p.nbn > 0) {
+        // sets: for each term t: r1 (set 0) -> rstats[t] slot 0 ; r2 (set 1+t) -> rstats[t] slot 1
+        double* dst[5];
+        int which[5];
+        float(*sel)[8] = acc;
+        // first flush r2 sets + one r1; r1 is shared by all terms, so add it to each term's buffer
+        for (int t = 0; t < p.nbn; ++t) {
+            dst[0] = p.rstats[t], which[0] = 0;
+            dst[1] = p.rstats[t], which[1] = 1;
+            float two[2][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) two[0][j] = sel[0][j], two[1][j] = sel[1 + t][j];
+            flush_sets<2>(two, red, C, VPC, dst, which, 2);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- upsample backward
+template <typename T>
+__global__ void upsample_bwd_kernel(const stl_upbwd p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int C = p.C, VPC = C >> 3;
+    float* mu = reinterpret_cast<float*>(smem);  // [2][C]
+    float* red = mu + 2 * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float m, r;
+        bn_mean_rstd(p.bn, c, C, m, r);
+        mu[c] = m, mu[C + c] = r;
+    }
+    __syncthreads();
+    float acc[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[s][j] = 0.f;
+    const int f = 1 << p.shift, Hh = p.H << p.shift, Wh = p.W << p.shift;
+    const size_t total = (size_t)p.B * p.H * p.W * VPC;
+    const int cg = threadIdx.x % VPC, c0 = cg * 8;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (size_t)gridDim.x * blockDim.x) {
+        const size_t pi = v / VPC;
+        const int x = (int)(pi % p.W);
+        const size_t by = pi / p.W;
+        const int y = (int)(by % p.H), b = (int)(by / p.H);
+        float s[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = 0.f;
+        for (int dy = 0; dy < f; ++dy)
+            for (int dx = 0; dx < f; ++dx) {
+                const size_t off = (((size_t)b * Hh + (y * f + dy)) * Wh + (x * f + dx)) * C + c0;
+                float d[8];
+                load8<T>(p.du, off, d);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += d[j];
+            }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = round_to<T>(s[j]);
+        store8<T>(p.dt, pi * C + c0, s);
+        float yv[8];
+        load8<T>(p.bn.x, pi * C + c0, yv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc[0][j] += s[j];
+            acc[1][j] += s[j] * (yv[j] - mu[c0 + j]) * mu[C + c0 + j];
+        }
+    }
+    double* dst[2] = {p.rstats, p.rstats};
+    int which[2] = {0, 1};
+    flush_sets<2>(acc, red, C, VPC, dst, which, 2);
+}
+
+// ---------------------------------------------------------------- stem patches
+template <typename T>
+__global__ __launch_bounds__(256) void patch_kernel(const float* img, void* out, int B, int H, int W, int Ho, int Wo,
+                                                    int stride, const float* mean3, const float* std3) {
+    const size_t total = (size_t)B * Ho * Wo * 4;  // 4 vectors of 8 per pixel
+    float mean[3] = {0.f, 0.f, 0.f}, istd[3] = {1.f, 1.f, 1.f};
+    if (mean3) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) mean[c] = mean3[c], istd[c] = 1.f / std3[c];
+    }
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (size_t)gridDim.x * 256) {
+        const size_t pi = v >> 2;
+        const int part = (int)(v & 3);
+        const int ox = (int)(pi % Wo);
+        const size_t by = pi / Wo;
+        const int oy = (int)(by % Ho), b = (int)(by / Ho);
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kk = part * 8 + j;
+            float val = 0.f;
+            if (kk < 27) {
+                const int tap = kk / 3, c = kk - tap * 3;
+                const int iy = oy * stride + tap / 3 - 1, ix = ox * stride + tap % 3 - 1;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                    val = img[(((size_t)b * 3 + c) * H + iy) * W + ix];
+                    if (mean3) val = (val - mean[c]) / std3[c];
+                }
+            }
+            f[j] = val;
+        }
+        (void)istd;
+        store8<T>(out, pi * 32 + part * 8, f);
+    }
+}
+
+// ---------------------------------------------------------------- head
+template <typename T, int J>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const void* x, const float* w, const float* bias, float* out,
+                                                       int B, int HW, int Ci) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sw = reinterpret_cast<float*>(smem);  // [J][Ci]
+    for (int e = threadIdx.x; e < J * Ci; e += 256) sw[e] = w[e];
+    __syncthreads();
+    const size_t P = (size_t)B * HW;
+    for (size_t pi = (size_t)blockIdx.x * 256 + threadIdx.x; pi < P; pi += (size_t)gridDim.x * 256) {
+        float o[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) o[j] = bias ? bias[j] : 0.f;
+        for (int c0 = 0; c0 < Ci; c0 += 8) {
+            float f[8];
+            load8<T>(x, pi * Ci + c0, f);
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o[j] = fmaf(f[q], sw[j * Ci + c0 + q], o[j]);
+        }
+        const size_t b = pi / HW, hw = pi - b * HW;
+#pragma unroll
+        for (int j = 0; j < J; ++j) out[(b * J + j) * HW + hw] = o[j];
+    }
+}
+
+template <typename T, int J>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const void* x, const float* w, const float* dout, void* dx,
+                                                       float* partial, int B, int HW, int Ci) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sw = reinterpret_cast<float*>(smem);  // [J][Ci]
+    float* sd = sw + J * Ci;                     // [J][256]
+    float* sx = sd + J * 256;                    // [256][Ci+1]
+    for (int e = threadIdx.x; e < J * Ci; e += 256) sw[e] = w[e];
+    const int nel = J * Ci + J;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // up to 4 dw/db elements per thread (nel <= 1024)
+    const size_t P = (size_t)B * HW;
+    const size_t nchunk = (P + 255) / 256;
+    for (size_t ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+        const size_t pi = ch * 256 + threadIdx.x;
+        __syncthreads();
+        float d[J];
+        if (pi < P) {
+            const size_t b = pi / HW, hw = pi - b * HW;
+#pragma unroll
+            for (int j = 0; j < J; ++j) d[j] = dout[(b * J + j) * HW + hw];
+        } else {
+#pragma unroll
+            for (int j = 0; j < J; ++j) d[j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) sd[j * 256 + threadIdx.x] = d[j];
+        for (int c0 = 0; c0 < Ci; c0 += 8) {
+            float f[8], gx[8];
+            if (pi < P) {
+                load8<T>(x, pi * Ci + c0, f);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) f[q] = 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                sx[threadIdx.x * (Ci + 1) + c0 + q] = f[q];
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < J; ++j) s = fmaf(d[j], sw[j * Ci + c0 + q], s);
+                gx[q] = s;
+            }
+            if (pi < P) store8<T>(dx, pi * Ci + c0, gx);
+        }
+        __syncthreads();
+        for (int r = 0; r < 4; ++r) {
+            const int e = threadIdx.x + r * 256;
+            if (e >= nel) break;
+            float s = 0.f;
+            if (e < J * Ci) {
+                const int j = e / Ci, c = e - j * Ci;
+                for (int q = 0; q < 256; ++q) s = fmaf(sd[j * 256 + q], sx[q * (Ci + 1) + c], s);
+            } else {
+                const int j = e - J * Ci;
+                for (int q = 0; q < 256; ++q) s += sd[j * 256 + q];
+            }
+            if (r == 0) a0 += s; else if (r == 1) a1 += s; else if (r == 2) a2 += s; else a3 += s;
+        }
+    }
+    for (int r = 0; r < 4; ++r) {
+        const int e = threadIdx.x + r * 256;
+        if (e < nel) partial[(size_t)blockIdx.x * nel + e] = r == 0 ? a0 : r == 1 ? a1 : r == 2 ? a2 : a3;
+    }
+}
+
+// ---------------------------------------------------------------- loss
+__global__ __launch_bounds__(256) void mse_kernel(const float* o, const float* t, const float* tw, float* dout,
+                                                  double* partial, size_t n, int HW, float gs) {
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float w = tw[i / HW];
+        const float d = (o[i] - t[i]) * w;
+        acc += (double)d * (double)d;
+        if (dout) dout[i] = d * w * gs;
+    }
+    __shared__ double sred[4];
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sred[0] + sred[1] + sred[2] + sred[3];
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* partial, int n, double scale, float* out, int accumulate) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    __shared__ double sred[4];
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double s = (sred[0] + sred[1] + sred[2] + sred[3]) * scale;
+        out[0] = (float)((accumulate ? (double)out[0] : 0.0) + s);
+    }
+}
+
+// ---------------------------------------------------------------- decode
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) {
+    // np.argmax order: NaN beats everything, then larger value, ties -> smaller index
+    const bool vn = v != v, bn = bv != bv;
+    if (vn != bn) return vn;
+    if (vn) return i < bi;
+    return v > bv || (v == bv && i < bi);
+}
+__device__ __forceinline__ void block_argmax(const float* row, int n, float& bv, int& bi, float* sv, int* si) {
+    bv = -INFINITY, bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = row[i];
+        if (bi == 0x7fffffff || better(v, i, bv, bi)) bv = v, bi = i;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || better(ov, oi, bv, bi))) bv = ov, bi = oi;
+    }
+    if ((threadIdx.x & 63) == 0) sv[threadIdx.x >> 6] = bv, si[threadIdx.x >> 6] = bi;
+    __syncthreads();
+    bv = sv[0], bi = si[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+        if (si[w] != 0x7fffffff && (bi == 0x7fffffff || better(sv[w], si[w], bv, bi))) bv = sv[w], bi = si[w];
+}
+
+__global__ __launch_bounds__(256) void argmax_kernel(const float* hm, int32_t* idx, float* maxval, float* preds, int H, int W) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const float* row = hm + (size_t)blockIdx.x * H * W;
+    float bv;
+    int bi;
+    block_argmax(row, H * W, bv, bi, sv, si);
+    if (threadIdx.x == 0) {
+        if (idx) idx[blockIdx.x] = bi;
+        maxval[blockIdx.x] = bv;
+        const float m = bv > 0.f ? 1.f : 0.f;
+        preds[2 * blockIdx.x] = (float)(bi % W) * m;
+        preds[2 * blockIdx.x + 1] = (float)(bi / W) * m;
+    }
+}
+
+__global__ __launch_bounds__(256) void final_preds_kernel(const float* hm, const float* center, const float* scale,
+                                                          float* preds, float* maxval, int J, int H, int W) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const float* row = hm + (size_t)blockIdx.x * H * W;
+    float bv;
+    int bi;
+    block_argmax(row, H * W, bv, bi, sv, si);
+    if (threadIdx.x == 0) {
+        const float m = bv > 0.f ? 1.f : 0.f;
+        float cx = (float)(bi % W) * m, cy = (float)(bi / W) * m;
+        const int px = (int)floorf(cx + 0.5f), py = (int)floorf(cy + 0.5f);
+        if (1 < px && px < W - 1 && 1 < py && py < H - 1) {
+            const float dx = row[py * W + px + 1] - row[py * W + px - 1];
+            const float dy = row[(py + 1) * W + px] - row[(py - 1) * W + px];
+            cx += (dx > 0.f) ? 0.25f : (dx < 0.f ? -0.25f : 0.f);
+            cy += (dy > 0.f) ? 0.25f : (dy < 0.f ? -0.25f : 0.f);
+        }
+        const int b = blockIdx.x / J;
+        // inverse of the crop transform (rot = 0): scale s = W / (scale_x * 200) on both axes
+        const double s = (double)W / ((double)scale[2 * b] * 200.0);
+        preds[2 * blockIdx.x] = (float)(((double)cx - 0.5 * W) / s + (double)center[2 * b]);
+        preds[2 * blockIdx.x + 1] = (float)(((double)cy - 0.5 * H) / s + (double)center[2 * b + 1]);
+        maxval[blockIdx.x] = bv;
+    }
+}
+
+__global__ __launch_bounds__(256) void flip_merge_kernel(const float* a, const float* bf, float* out, const int32_t* perm,
+                                                         int J, int H, int W, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % W);
+        const size_t r = i / W;
+        const int y = (int)(r % H);
+        const size_t bj = r / H;
+        const int j = (int)(bj % J);
+        const size_t b = bj / J;
+        const int xs = x > 0 ? x - 1 : 0;  // 1-px right shift, column 0 keeps its own value
+        const float f = bf[((b * J + perm[j]) * H + y) * W + (W - 1 - xs)];
+        out[i] = 0.5f * (a[i] + f);
+    }
+}
+
+// ---------------------------------------------------------------- batched tables
+__device__ __forceinline__ int find_entry(const int* blk0_first, int stride_ints, int n, int blk) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (blk0_first[(size_t)mid * stride_ints] <= blk) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prep_kernel(const float* master, T* wk, const stl_wprep* tab, int n) {
+    const int ei = find_entry(&tab[0].blk0, sizeof(stl_wprep) / 4, n, blockIdx.x);
+    const stl_wprep e = tab[ei];
+    const int t = e.ks * e.ks;
+    const int64_t tot = (int64_t)e.Co * e.Ci * t;
+    const int64_t base = (int64_t)(blockIdx.x - e.blk0) * 1024;
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = base + r * 256 + threadIdx.x;
+        if (i >= tot) return;
+        const int co = (int)(i / (e.Ci * t)), rem = (int)(i - (int64_t)co * e.Ci * t), ci = rem / t, tap = rem - ci * t;
+        const float v = master[e.src_off + i];
+        if (e.patch)
+            wk[e.fwd_off + (int64_t)co * e.Cip + tap * e.Ci + ci] = (T)v;
+        else
+            wk[e.fwd_off + ((int64_t)co * t + tap) * e.Cip + ci] = (T)v;
+        if (e.bwd_off >= 0) wk[e.bwd_off + ((int64_t)ci * t + (t - 1 - tap)) * e.Co + co] = (T)v;
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* partials, float* grads, const stl_slab* tab, int n) {
+    const int ei = find_entry(&tab[0].blk0, sizeof(stl_slab) / 4, n, blockIdx.x);
+    const stl_slab e = tab[ei];
+    const int t = e.ks * e.ks;
+    const int64_t tot = (int64_t)e.Co * e.Ci * t;
+    const int tk = e.patch ? 1 : t, cik = e.patch ? e.Cip : e.Ci;
+    const int64_t slab = e.pad ? (int64_t)e.pad : (int64_t)e.Co * tk * cik;
+    const int64_t base = (int64_t)(blockIdx.x - e.blk0) * 1024;
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = base + r * 256 + threadIdx.x;
+        if (i >= tot) return;
+        const int co = (int)(i / (e.Ci * t)), rem = (int)(i - (int64_t)co * e.Ci * t), ci = rem / t, tap = rem - ci * t;
+        const int64_t src = e.patch ? ((int64_t)co * cik + tap * e.Ci + ci) : (((int64_t)co * t + tap) * cik + ci);
+        float s = 0.f;
+        for (int k = 0; k < e.nsplit; ++k) s += partials[e.part_off + k * slab + src];
+        grads[e.grad_off + i] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_running_kernel(const double* stats, float* buffers, int64_t* nbt,
+                                                         const stl_bnrec* tab, float momentum) {
+    const stl_bnrec e = tab[blockIdx.x];
+    const double n = 1.0 / (double)e.inv_count;
+    for (int c = threadIdx.x; c < e.C; c += 256) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int k = 0; k < STL_NSHARD; ++k) {
+            s0 += stats[e.stats_off + (int64_t)k * 2 * e.C + c];
+            s1 += stats[e.stats_off + (int64_t)k * 2 * e.C + e.C + c];
+        }
+        const double mean = s0 / n;
+        double var = s1 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+        float* rm = buffers + e.buf_off;
+        float* rv = rm + e.C;
+        rm[c] = (float)((1.0 - momentum) * (double)rm[c] + momentum * mean);
+        rv[c] = (float)((1.0 - momentum) * (double)rv[c] + momentum * unb);
+    }
+    if (threadIdx.x == 0 && nbt) nbt[blockIdx.x] += 1;
+}
+
+__global__ __launch_bounds__(256) void bn_param_grads_kernel(const double* rstats, float* grads, const stl_bnrec* tab) {
+    const stl_bnrec e = tab[blockIdx.x];
+    for (int c = threadIdx.x; c < e.C; c += 256) {
+        double r1 = 0.0, r2 = 0.0;
+        for (int k = 0; k < STL_NSHARD; ++k) {
+            r1 += rstats[e.stats_off + (int64_t)k * 2 * e.C + c];
+            r2 += rstats[e.stats_off + (int64_t)k * 2 * e.C + e.C + c];
+        }
+        grads[e.param_off + c] = (float)r2;        // dgamma
+        grads[e.param_off + e.C + c] = (float)r1;  // dbeta
+    }
+}
+
+// ---------------------------------------------------------------- optimisers
+__global__ void inc_step_kernel(int32_t* step) { step[0] += 1; }
+
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n,
+                                                   const float* hyper, const int32_t* step) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], gs = hyper[7];
+    const int t = step[0];
+    const float bc1 = 1.f - powf(b1, (float)t), bc2 = 1.f - powf(b2, (float)t);
+    const float step_size = lr / bc1, isq2 = 1.f / sqrtf(bc2);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float gi = g[i] * gs;
+        const float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi, v[i] = vi;
+        p[i] = pi - step_size * mi / (sqrtf(vi) * isq2 + eps);
+    }
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, float* mom, int64_t n, const float* hyper,
+                                                  const int32_t* step) {
+    const float lr = hyper[0], wd = hyper[4], mu = hyper[5], nest = hyper[6], gs = hyper[7];
+    const bool first = step[0] <= 1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float gi = g[i] * gs;
+        const float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        if (mu != 0.f) {
+            const float b = first ? gi : mu * mom[i] + gi;
+            mom[i] = b;
+            gi = nest != 0.f ? gi + mu * b : b;
+        }
+        p[i] = pi - lr * gi;
+    }
+}
+
+// ---------------------------------------------------------------- VGG helpers
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const void* x, void* out, int B, int H, int W, int C) {
+    const int Ho = H >> 1, Wo = W >> 1, VPC = C >> 3;
+    const size_t total = (size_t)B * Ho * Wo * VPC;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (size_t)gridDim.x * 256) {
+        const size_t pi = v / VPC;
+        const int c0 = (int)(v - pi * VPC) * 8;
+        const int ox = (int)(pi % Wo);
+        const size_t by = pi / Wo;
+        const int oy = (int)(by % Ho), b = (int)(by / Ho);
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+        for (int dy = 0; dy < 2; ++dy)
+            for (int dx = 0; dx < 2; ++dx) {
+                float f[8];
+                load8<T>(x, (((size_t)b * H + 2 * oy + dy) * W + 2 * ox + dx) * C + c0, f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], f[j]);
+            }
+        store8<T>(out, pi * C + c0, m);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void l1_kernel(const void* a, const void* b, size_t nvec, double* partial) {
+    double acc = 0.0;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (size_t)gridDim.x * 256) {
+        float x[8], y[8];
+        load8<T>(a, v * 8, x);
+        load8<T>(b, v * 8, y);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += fabsf(x[j] - y[j]);
+        acc += (double)s;
+    }
+    __shared__ double sred[4];
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sred[0] + sred[1] + sred[2] + sred[3];
+}
+
+__global__ __launch_bounds__(256) void bilinear_kernel(const float* in, float* out, int BC, int H, int W, int Ho, int Wo) {
+    const float sy = (float)H / Ho, sx = (float)W / Wo;
+    const size_t total = (size_t)BC * Ho * Wo;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int ox = (int)(i % Wo);
+        const size_t r = i / Wo;
+        const int oy = (int)(r % Ho);
+        const size_t bc = r / Ho;
+        float fy = sy * (oy + 0.5f) - 0.5f, fx = sx * (ox + 0.5f) - 0.5f;
+        if (fy < 0.f) fy = 0.f;
+        if (fx < 0.f) fx = 0.f;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly = fy - y0, lx = fx - x0;
+        const float* p = in + bc * H * W;
+        out[i] = (1.f - ly) * ((1.f - lx) * p[y0 * W + x0] + lx * p[y0 * W + x1]) +
+                 ly * ((1.f - lx) * p[y1 * W + x0] + lx * p[y1 * W + x1]);
+    }
+}
+
+// ---------------------------------------------------------------- layout
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* in, T* out, int B, int C, int HW) {
+    const size_t total = (size_t)B * C * HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const size_t r = i / C;
+        const size_t hw = r % HW, b = r / HW;
+        out[i] = (T)in[(b * C + c) * HW + hw];
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* in, float* out, int B, int C, int HW) {
+    const size_t total = (size_t)B * C * HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t hw = i % HW;
+        const size_t r = i / HW;
+        const int c = (int)(r % C);
+        const size_t b = r / C;
+        out[i] = (float)in[(b * HW + hw) * C + c];
+    }
+}
+
+// ---------------------------------------------------------------- self test
+__global__ void selftest_kernel(float* out) {
+    __shared__ __attribute__((aligned(16))) unsigned short tile[32 * 16];  // [32 k][16 cols] bf16
+    __shared__ float ref[16 * 16];
+    const int lane = threadIdx.x, r16 = lane & 15, g = lane >> 4;
+    // A[m][k] = ((m*3 + k*5) % 7) - 3, B[k][n] = ((k*2 + n*7) % 5) - 2  (exact in bf16; asymmetric)
+    float err_bf = 0.f, err_f32 = 0.f;
+    {
+        V16 a, b;
+        float fa[8], fb[8];
+        for (int j = 0; j < 8; ++j) {
+            const int kk = 8 * g + j;
+            fa[j] = (float)(((r16 * 3 + kk * 5) % 7) - 3);
+            fb[j] = (float)(((kk * 2 + r16 * 7) % 5) - 2);
+        }
+        a = pack<__bf16>(fa), b = pack<__bf16>(fb);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        mma16<__bf16>(acc, a, b);
+        for (int r = 0; r < 4; ++r) {
+            const int m = 4 * g + r, nn = r16;
+            float s = 0.f;
+            for (int kk = 0; kk < 32; ++kk) s += (float)(((m * 3 + kk * 5) % 7) - 3) * (float)(((kk * 2 + nn * 7) % 5) - 2);
+            err_bf = fmaxf(err_bf, fabsf(s - acc[r]));
+        }
+    }
+    {
+        V16 a, b;
+        float fa[4], fb[4];
+        for (int s = 0; s < 4; ++s) {
+            const int kk = 4 * g + s;
+            fa[s] = (float)(((r16 * 3 + kk * 5) % 7) - 3);
+            fb[s] = (float)(((kk * 2 + r16 * 7) % 5) - 2);
+        }
+        a = pack<float>(fa), b = pack<float>(fb);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        mma16<float>(acc, a, b);
+        for (int r = 0; r < 4; ++r) {
+            const int m = 4 * g + r, nn = r16;
+            float s = 0.f;
+            for (int kk = 0; kk < 16; ++kk) s += (float)(((m * 3 + kk * 5) % 7) - 3) * (float)(((kk * 2 + nn * 7) % 5) - 2);
+            err_f32 = fmaxf(err_f32, fabsf(s - acc[r]));
+        }
+    }
+    // transposed LDS read: tile[k][col] = k*16 + col ; expect lane (col = r16, group g) to get
+    // rows 8g+4h+{0..3} of column r16
+    for (int e = lane; e < 32 * 16; e += 64) tile[e] = (unsigned short)e;
+    __syncthreads();
+    float err_tr = 0.f;
+    for (int h = 0; h < 2; ++h) {
+        const int row = 8 * g + 4 * h + (r16 >> 2);
+        const char* ptr = (const char*)tile + row * 32 + (lane & 3) * 8;
+        s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(uintptr_t)(uint32_t)(uintptr_t)ptr);
+        for (int q = 0; q < 4; ++q) {
+            const int expect = (8 * g + 4 * h + q) * 16 + r16;
+            err_tr = fmaxf(err_tr, fabsf((float)(unsigned short)r[q] - (float)expect));
+        }
+    }
+    (void)ref;
+    err_bf = wave_sum(err_bf), err_f32 = wave_sum(err_f32), err_tr = wave_sum(err_tr);
+    if (lane == 0) out[0] = err_bf, out[1] = err_f32, out[2] = err_tr;
+}
+__global__ void selftest_atomic_kernel(double* d) { atomicAdd(d + (threadIdx.x & 1), 0.5); }
+__global__ void selftest_fin_kernel(const double* d, float* out) { out[3] = (float)fabs(d[0] - 64.0) + (float)fabs(d[1] - 64.0); }
+
+inline int nblocks_for(size_t work, int per_block = 256, int cap = 2048) {
+    size_t b = (work + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > (size_t)cap) b = cap;
+    return (int)b;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int stl_fuse_forward(const stl_fuse* pp, void* stream) {
+    const stl_fuse& p = *pp;
+    STL_CHECK(p.C % 8 == 0 && p.C > 0 && p.C <= 1024, "fuse: C=%d must be a multiple of 8 (<=1024)", p.C);
+    STL_CHECK(p.nterms >= 1 && p.nterms <= 4, "fuse: nterms %d", p.nterms);
+    for (int t = 0; t < p.nterms; ++t) {
+        STL_CHECK(p.t[t].src.x, "fuse: null term %d", t);
+        STL_CHECK(p.t[t].src.mode == STL_SRC_PLAIN || p.t[t].src.mode == STL_SRC_BN, "fuse: term mode");
+        STL_CHECK(p.t[t].shift >= 0 && p.t[t].shift <= 4 && (p.H % (1 << p.t[t].shift)) == 0 && (p.W % (1 << p.t[t].shift)) == 0,
+                  "fuse: %dx%d not divisible by 2^%d", p.H, p.W, p.t[t].shift);
+    }
+    const size_t total = (size_t)p.B * p.H * p.W * (p.C / 8);
+    const size_t lds = (size_t)p.nterms * 2 * p.C * 4;
+    if (p.dtype == STL_BF16)
+        hipLaunchKernelGGL(fuse_fwd_kernel<__bf16>, dim3(nblocks_for(total)), dim3(256), lds, ST, p);
+    else
+        hipLaunchKernelGGL(fuse_fwd_kernel<float>, dim3(nblocks_for(total)), dim3(256), lds, ST, p);
+    STL_LAUNCH_CHECK("fuse_forward");
+    return 0;
+}
+
+static int stat_block(int C) {
+    const int vpc = C / 8;
+    return vpc * (256 / vpc);
+}
+
+extern "C" int stl_fuse_backward(const stl_fuse_bwd* pp, void* stream) {
+    const stl_fuse_bwd& p = *pp;
+    STL_CHECK(p.C % 8 == 0 && p.C > 0 && p.C <= 1024, "fuse_bwd: C=%d", p.C);
+    STL_CHECK(p.ngrads >= 1 && p.ngrads <= 4 && p.nbn >= 0 && p.nbn <= 4, "fuse_bwd: ngrads/nbn");
+    STL_CHECK(!p.relu || p.z, "fuse_bwd: relu needs z");
+    for (int t = 0; t < p.nbn; ++t) STL_CHECK(p.bn[t].x && p.bn[t].stats && p.rstats[t], "fuse_bwd: bn term %d incomplete", t);
+    const int bd = stat_block(p.C);
+    const size_t total = (size_t)p.B * p.H * p.W * (p.C / 8);
+    int nb = nblocks_for(total, bd, 512);
+    const size_t lds = (size_t)(p.nbn > 0 ? p.nbn : 1) * 2 * p.C * 4 + (size_t)bd * 2 * 8 * 4;
+    if (p.dtype == STL_BF16)
+        hipLaunchKernelGGL(fuse_bwd_kernel<__bf16>, dim3(nb), dim3(bd), lds, ST, p);
+    else
+        hipLaunchKernelGGL(fuse_bwd_kernel<float>, dim3(nb), dim3(bd), lds, ST, p);
+    STL_LAUNCH_CHECK("fuse_backward");
+    return 0;
+}
+
+extern "C" int stl_upsample_backward(const stl_upbwd* pp, void* stream) {
+    const stl_upbwd& p = *pp;
+    STL_CHECK(p.C % 8 == 0 && p.C > 0 && p.C <= 1024, "upsample_bwd: C=%d", p.C);
+    STL_CHECK(p.shift >= 1 && p.shift <= 4, "upsample_bwd: shift %d", p.shift);
+    STL_CHECK(p.du && p.dt && p.bn.x && p.bn.stats && p.rstats, "upsample_bwd: null pointer");
+    const int bd = stat_block(p.C);
+    const size_t total = (size_t)p.B * p.H * p.W * (p.C / 8);
+    int nb = nblocks_for(total, bd, 512);
+    const size_t lds = (size_t)2 * p.C * 4 + (size_t)bd * 2 * 8 * 4;
+    if (p.dtype == STL_BF16)
+        hipLaunchKernelGGL(upsample_bwd_kernel<__bf16>, dim3(nb), dim3(bd), lds, ST, p);
+    else
+        hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(nb), dim3(bd), lds, ST, p);
+    STL_LAUNCH_CHECK("upsample_backward");
+    return 0;
+}
+
+extern "C" int stl_patch3x3(int dtype, const float* img, void* out, int B, int H, int W, int stride, const float* mean3,
+                            const float* std3, void* stream) {
+    STL_CHECK(stride == 1 || stride == 2, "patch3x3: stride");
+    STL_CHECK(img && out && B > 0 && H > 0 && W > 0, "patch3x3: bad args");
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const size_t total = (size_t)B * Ho * Wo * 4;
+    if (dtype == STL_BF16)
+        hipLaunchKernelGGL(patch_kernel<__bf16>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, img, out, B, H, W, Ho, Wo, stride, mean3, std3);
+    else
+        hipLaunchKernelGGL(patch_kernel<float>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, img, out, B, H, W, Ho, Wo, stride, mean3, std3);
+    STL_LAUNCH_CHECK("patch3x3");
+    return 0;
+}
+
+extern "C" int stl_head_forward(int dtype, const void* x, const float* w, const float* bias, float* out, int B, int H, int W,
+                                int Ci, int J, void* stream) {
+    STL_CHECK(J == 17 || J == 16, "head: J=%d unsupported (16 or 17)", J);
+    STL_CHECK(Ci % 8 == 0 && Ci <= 512, "head: Ci=%d", Ci);
+    const size_t P = (size_t)B * H * W;
+    const size_t lds = (size_t)J * Ci * 4;
+    const dim3 grid(nblocks_for(P));
+#define HF(T, JJ) hipLaunchKernelGGL((head_fwd_kernel<T, JJ>), grid, dim3(256), lds, ST, x, w, bias, out, B, H * W, Ci)
+    if (dtype == STL_BF16) { if (J == 17) HF(__bf16, 17); else HF(__bf16, 16); }
+    else { if (J == 17) HF(float, 17); else HF(float, 16); }
+#undef HF
+    STL_LAUNCH_CHECK("head_forward");
+    return 0;
+}
+
+extern "C" int stl_head_backward(int dtype, const void* x, const float* w, const float* dout, void* dx, float* partial,
+                                 int nblk, int B, int H, int W, int Ci, int J, void* stream) {
+    STL_CHECK(J == 17 || J == 16, "head_bwd: J=%d unsupported", J);
+    STL_CHECK(Ci % 8 == 0 && J * Ci + J <= 1024, "head_bwd: Ci=%d", Ci);
+    STL_CHECK(nblk >= 1, "head_bwd: nblk");
+    const size_t lds = (size_t)(J * Ci + J * 256 + 256 * (Ci + 1)) * 4;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<__bf16, 17>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<__bf16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<float, 17>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<float, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+#define HB(T, JJ) hipLaunchKernelGGL((head_bwd_kernel<T, JJ>), dim3(nblk), dim3(256), lds, ST, x, w, dout, dx, partial, B, H * W, Ci)
+    if (dtype == STL_BF16) { if (J == 17) HB(__bf16, 17); else HB(__bf16, 16); }
+    else { if (J == 17) HB(float, 17); else HB(float, 16); }
+#undef HB
+    STL_LAUNCH_CHECK("head_backward");
+    return 0;
+}
+
+extern "C" int stl_sum_partials(const double* partial, int n, double scale, float* out, int accumulate, void* stream) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ST, partial, n, scale, out, accumulate);
+    STL_LAUNCH_CHECK("sum_partials");
+    return 0;
+}
+
+extern "C" int stl_mse_loss(const float* out, const float* target, const float* tweight, float* dout, double* partial,
+                            int nblk, float* loss, int B, int J, int HW, float gscale, void* stream) {
+    STL_CHECK(out && target && tweight && partial && loss && nblk >= 1, "mse: null pointer");
+    const size_t n = (size_t)B * J * HW;
+    hipLaunchKernelGGL(mse_kernel, dim3(nblk), dim3(256), 0, ST, out, target, tweight, dout, partial, n, HW, gscale / (float)n);
+    STL_LAUNCH_CHECK("mse_loss");
+    return stl_sum_partials(partial, nblk, 0.5 / (double)n, loss, 0, stream);
+}
+
+extern "C" int stl_heatmap_argmax(const float* hm, int32_t* idx, float* maxval, float* preds, int BJ, int H, int W, void* stream) {
+    if (BJ == 0) return 0;
+    STL_CHECK(hm && maxval && preds && H > 0 && W > 0, "argmax: bad args");
+    hipLaunchKernelGGL(argmax_kernel, dim3(BJ), dim3(256), 0, ST, hm, idx, maxval, preds, H, W);
+    STL_LAUNCH_CHECK("heatmap_argmax");
+    return 0;
+}
+
+extern "C" int stl_final_preds(const float* hm, const float* center, const float* scale, float* preds, float* maxval, int B,
+                               int J, int H, int W, void* stream) {
+    if (B * J == 0) return 0;
+    hipLaunchKernelGGL(final_preds_kernel, dim3(B * J), dim3(256), 0, ST, hm, center, scale, preds, maxval, J, H, W);
+    STL_LAUNCH_CHECK("final_preds");
+    return 0;
+}
+
+extern "C" int stl_flip_merge(const float* a, const float* bflip, float* out, const int32_t* perm, int B, int J, int H, int W,
+                              void* stream) {
+    const size_t n = (size_t)B * J * H * W;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(flip_merge_kernel, dim3(nblocks_for(n)), dim3(256), 0, ST, a, bflip, out, perm, J, H, W, n);
+    STL_LAUNCH_CHECK("flip_merge");
+    return 0;
+}
+
+extern "C" int stl_weight_prep(int dtype, const float* master, void* wk, const stl_wprep* tab, int n, int nblocks, void* stream) {
+    if (n == 0) return 0;
+    if (dtype == STL_BF16)
+        hipLaunchKernelGGL(weight_prep_kernel<__bf16>, dim3(nblocks), dim3(256), 0, ST, master, (__bf16*)wk, tab, n);
+    else
+        hipLaunchKernelGGL(weight_prep_kernel<float>, dim3(nblocks), dim3(256), 0, ST, master, (float*)wk, tab, n);
+    STL_LAUNCH_CHECK("weight_prep");
+    return 0;
+}
+
+extern "C" int stl_reduce_slabs(const float* partials, float* grads, const stl_slab* tab, int n, int nblocks, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(nblocks), dim3(256), 0, ST, partials, grads, tab, n);
+    STL_LAUNCH_CHECK("reduce_slabs");
+    return 0;
+}
+
+extern "C" int stl_bn_running_update(const double* stats, float* buffers, int64_t* nbt, const stl_bnrec* tab, int n,
+                                     float momentum, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(bn_running_kernel, dim3(n), dim3(256), 0, ST, stats, buffers, nbt, tab, momentum);
+    STL_LAUNCH_CHECK("bn_running_update");
+    return 0;
+}
+
+extern "C" int stl_bn_param_grads(const double* rstats, float* grads, const stl_bnrec* tab, int n, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(bn_param_grads_kernel, dim3(n), dim3(256), 0, ST, rstats, grads, tab);
+    STL_LAUNCH_CHECK("bn_param_grads");
+    return 0;
+}
+
+extern "C" int stl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, int32_t* step, void* stream) {
+    hipLaunchKernelGGL(inc_step_kernel, dim3(1), dim3(1), 0, ST, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(nblocks_for((size_t)n, 256, 4096)), dim3(256), 0, ST, p, g, m, v, n, hyper, step);
+    STL_LAUNCH_CHECK("adam_step");
+    return 0;
+}
+
+extern "C" int stl_sgd_step(float* p, const float* g, float* mom, int64_t n, const float* hyper, int32_t* step, void* stream) {
+    hipLaunchKernelGGL(inc_step_kernel, dim3(1), dim3(1), 0, ST, step);
+    hipLaunchKernelGGL(sgd_kernel, dim3(nblocks_for((size_t)n, 256, 4096)), dim3(256), 0, ST, p, g, mom, n, hyper, step);
+    STL_LAUNCH_CHECK("sgd_step");
+    return 0;
+}
+
+extern "C" int stl_maxpool2x2(int dtype, const void* x, void* out, int B, int H, int W, int C, void* stream) {
+    STL_CHECK(C % 8 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool: C%%8 / even H,W required");
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
+    if (dtype == STL_BF16)
+        hipLaunchKernelGGL(maxpool_kernel<__bf16>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, x, out, B, H, W, C);
+    else
+        hipLaunchKernelGGL(maxpool_kernel<float>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, x, out, B, H, W, C);
+    STL_LAUNCH_CHECK("maxpool2x2");
+    return 0;
+}
+
+extern "C" int stl_l1_partial(int dtype, const void* a, const void* b, int64_t n, double* partial, int nblk, void* stream) {
+    STL_CHECK(n % 8 == 0 && nblk >= 1, "l1: n%%8");
+    if (dtype == STL_BF16)
+        hipLaunchKernelGGL(l1_kernel<__bf16>, dim3(nblk), dim3(256), 0, ST, a, b, (size_t)n / 8, partial);
+    else
+        hipLaunchKernelGGL(l1_kernel<float>, dim3(nblk), dim3(256), 0, ST, a, b, (size_t)n / 8, partial);
+    STL_LAUNCH_CHECK("l1_partial");
+    return 0;
+}
+
+extern "C" int stl_bilinear_nchw(const float* in, float* out, int B, int C, int H, int W, int Ho, int Wo, void* stream) {
+    const size_t total = (size_t)B * C * Ho * Wo;
+    hipLaunchKernelGGL(bilinear_kernel, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, in, out, B * C, H, W, Ho, Wo);
+    STL_LAUNCH_CHECK("bilinear");
+    return 0;
+}
+
+extern "C" int stl_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H, int W, void* stream) {
+    const size_t total = (size_t)B * C * H * W;
+    if (dtype == STL_BF16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, in, (__bf16*)out, B, C, H * W);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, in, (float*)out, B, C, H * W);
+    STL_LAUNCH_CHECK("nchw_to_nhwc");
+    return 0;
+}
+
+extern "C" int stl_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H, int W, void* stream) {
+    const size_t total = (size_t)B * C * H * W;
+    if (dtype == STL_BF16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, (const __bf16*)in, out, B, C, H * W);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, (const float*)in, out, B, C, H * W);
+    STL_LAUNCH_CHECK("nhwc_to_nchw");
+    return 0;
+}
+
+extern "C" int stl_selftest_mfma(float* out, void* stream) {
+    double* d = nullptr;
+    if (hipMalloc(&d, 16) != hipSuccess) return stl_set_error("selftest: hipMalloc failed");
+    hipMemsetAsync(d, 0, 16, ST);
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, ST, out);
+    hipLaunchKernelGGL(selftest_atomic_kernel, dim3(1), dim3(256), 0, ST, d);
+    hipLaunchKernelGGL(selftest_fin_kernel, dim3(1), dim3(1), 0, ST, d, out);
+    hipStreamSynchronize(ST);
+    hipFree(d);
+    STL_LAUNCH_CHECK("selftest");
+    return 0;
+}

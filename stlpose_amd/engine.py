@@ -1,0 +1,484 @@
+"""Static execution planner for the HRNet hot path on MI355X.
+
+The network topology (``arch.walk``) is turned ONCE per (batch, resolution, dtype, mode) into two
+flat lists of C-ABI kernel invocations with every device pointer resolved -- a forward program and
+its hand-derived backward program -- which are then replayed eagerly or captured in a HIP graph.
+No tracing compiler and no autograd tape at run time: the backward program is built here by a
+reverse walk over the plan (``_build_backward``).
+
+Data flow choices:
+  * activations NHWC, dtype bf16 or fp32, fp32 accumulation, fp64 BatchNorm statistics;
+  * a conv writes its RAW output plus per-channel sums; the BatchNorm (+ReLU) is applied by the
+    consumer while it stages its input ("normalise on load"), so BN costs no HBM pass of its own;
+  * residual adds / exchange sums are the only materialised activations (``fuse``);
+  * backward mirrors it: the data-gradient conv masks with the ReLU and reduces the BatchNorm
+    backward sums in its epilogue, and dgrad/wgrad apply the BatchNorm backward on load.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import capi
+from .arch import Arch, Registry, registry, walk
+
+EPS = 1e-5       # nn.BatchNorm2d default
+MOMENTUM = 0.1   # reference HRnet.py:23 (fuse/transition BNs use the default, also 0.1)
+
+
+def _esz(dtype: int) -> int:
+    return 2 if dtype == capi.BF16 else 4
+
+
+def choose_tile(B: int, Ho: int, Wo: int, stride: int, ks: int, esz: int, bn_cols: int = 64) -> Tuple[int, int]:
+    """Pick the output tile (TH virtual rows x TW columns, TH*TW <= 128) that wastes the fewest
+    MFMA rows / halo loads while fitting LDS."""
+    vrows = B * (Ho + 1)
+    best, best_tile = -1.0, (1, min(Wo, 128))
+    for tw in range(min(Wo, 4), min(Wo, 128) + 1):
+        th = max(1, min(128 // tw, vrows))
+        hr, hc = (th - 1) * stride + ks, (tw - 1) * stride + ks
+        lds = hr * hc * 80 + bn_cols * (ks * ks * 64 + 16) + 8192
+        if lds > 150 * 1024:
+            continue
+        cols = math.ceil(Wo / tw) * tw
+        rows = math.ceil(vrows / th) * th
+        eff = (Wo / cols) * (B * Ho / rows) * (th * tw / 128.0)
+        eff *= ((th * tw) / float(hr * hc) * stride * stride) ** 0.25  # mild halo penalty
+        if eff > best:
+            best, best_tile = eff, (th, tw)
+    return best_tile
+
+
+@dataclass
+class BNInfo:
+    idx: int
+    C: int
+    param_off: int   # gamma offset in master (beta at +C)
+    buf_off: int     # running_mean offset in float buffers (running_var at +C)
+    stats_off: int   # offset (doubles) in the stats / rstats arenas
+    inv_count: float = 0.0
+
+
+@dataclass
+class ConvInfo:
+    key: str
+    Co: int
+    Ci: int          # real input channels
+    ks: int
+    stride: int
+    patch: bool
+    master_off: int
+    fwd_off: int = -1
+    bwd_off: int = -1
+    Cik: int = 0     # input channels as the kernel sees them (32 for the patch conv)
+
+
+@dataclass
+class Act:
+    kind: str            # 'plain' | 'bn'
+    t: torch.Tensor      # storage (flat uint8)
+    B: int
+    H: int
+    W: int
+    C: int
+    bn: Optional[BNInfo] = None
+    relu: bool = False
+    needs_grad: bool = True
+    grads: List[torch.Tensor] = field(default_factory=list)  # plain: gradient contributions
+    dt: Optional[torch.Tensor] = None                        # bn: grad wrt BN output (masked)
+    consumers: int = 0
+
+    @property
+    def ptr(self) -> int:
+        return self.t.data_ptr()
+
+
+class ParamStore:
+    """Flat fp32 master / grad / buffer storage laid out in state_dict order."""
+
+    def __init__(self, reg: Registry, device):
+        self.reg = reg
+        self.param_off: Dict[str, int] = {}
+        off = 0
+        for k, s in reg.params:
+            self.param_off[k] = off
+            off += int(math.prod(s)) if s else 1
+        self.nparam = off
+        self.buf_off: Dict[str, int] = {}
+        self.nbt_idx: Dict[str, int] = {}
+        off, n = 0, 0
+        for k, s in reg.buffers:
+            if k.endswith("num_batches_tracked"):
+                self.nbt_idx[k] = n
+                n += 1
+            else:
+                self.buf_off[k] = off
+                off += int(math.prod(s))
+        self.nbuf, self.nnbt = off, n
+        self.device = device
+        self.master = torch.zeros(self.nparam, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(self.nparam, dtype=torch.float32, device=device)
+        self.bufs = torch.zeros(self.nbuf, dtype=torch.float32, device=device)
+        self.nbt = torch.zeros(self.nnbt, dtype=torch.int64, device=device)
+
+
+class Engine:
+    """One plan: fixed batch/resolution/dtype/mode."""
+
+    def __init__(self, arch: Arch, store: ParamStore, B: int, H: int, W: int, dtype: int, training: bool):
+        assert H % 32 == 0 and W % 32 == 0, "input H, W must be multiples of 32 (four stride-2 stages + 8x upsample)"
+        self.arch, self.store, self.B, self.H, self.W = arch, store, B, H, W
+        self.dtype, self.training = dtype, training
+        self.dev = store.device
+        self.esz = _esz(dtype)
+        self.tdtype = torch.bfloat16 if dtype == capi.BF16 else torch.float32
+        self.lib = capi.lib()
+        self.fwd_ops: List[Tuple] = []
+        self.bwd_ops: List[Tuple] = []
+        self.tape: List[Tuple] = []
+        self.convs: List[ConvInfo] = []
+        self.bns: List[BNInfo] = []
+        self._keep: List = []  # keep ctypes structs / tensors alive
+        self.act_bytes = 0
+        # static I/O
+        self.img = torch.zeros(B, 3, H, W, dtype=torch.float32, device=self.dev)
+        self.out: Optional[torch.Tensor] = None
+        self.dout: Optional[torch.Tensor] = None
+        # pass 1: count BN channels to size the statistics arenas
+        nstat = sum(int(math.prod(s)) for k, s in store.reg.params if _is_bn_weight(k, store.reg)) * 2 * capi.NSHARD
+        self.stats = torch.zeros(max(nstat, 1), dtype=torch.float64, device=self.dev)
+        self.rstats = torch.zeros(max(nstat, 1), dtype=torch.float64, device=self.dev) if training else None
+        self._stats_used = 0
+        self._wk_elems = 0
+        self._wk_fix: List[Tuple] = []
+        walk(self, arch)
+        self._finalize_weights()
+        if training:
+            self._build_backward()
+        self._build_tables()
+
+    # ------------------------------------------------------------------ allocation helpers
+    def _alloc(self, nbytes: int) -> torch.Tensor:
+        self.act_bytes += nbytes
+        return torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+
+    def _act_tensor(self, B, H, W, C) -> torch.Tensor:
+        return self._alloc(B * H * W * C * self.esz)
+
+    def _src(self, a: Act, relu: Optional[bool] = None) -> capi.Src:
+        s = capi.Src()
+        s.x = a.ptr
+        if a.kind == "plain":
+            s.mode = capi.SRC_PLAIN
+            return s
+        bn = a.bn
+        s.mode = capi.SRC_BN
+        s.relu = int(a.relu if relu is None else relu)
+        st = self.store
+        s.gamma = st.master.data_ptr() + 4 * bn.param_off
+        s.beta = st.master.data_ptr() + 4 * (bn.param_off + bn.C)
+        if self.training:
+            s.stats = self.stats.data_ptr() + 8 * bn.stats_off
+        else:
+            s.rmean = st.bufs.data_ptr() + 4 * bn.buf_off
+            s.rvar = st.bufs.data_ptr() + 4 * (bn.buf_off + bn.C)
+        s.inv_count = bn.inv_count
+        s.eps = EPS
+        return s
+
+    def _gsrc(self, y: Act) -> capi.Src:
+        """Gradient of a conv's raw output, BatchNorm backward applied on load."""
+        s = self._src(y)
+        s.mode = capi.SRC_BNBWD
+        s.x = y.dt.data_ptr()
+        s.y = y.ptr
+        s.rstats = self.rstats.data_ptr() + 8 * y.bn.stats_off
+        return s
+
+    # ------------------------------------------------------------------ builder protocol (arch.walk)
+    def stem_input(self) -> Act:
+        B, H, W = self.B, self.H, self.W
+        Ho, Wo = H // 2, W // 2
+        t = self._act_tensor(B, Ho, Wo, 32)
+        self.fwd_ops.append(("stl_patch3x3", (self.dtype, self.img.data_ptr(), t.data_ptr(), B, H, W, 2, None, None)))
+        return Act("plain", t, B, Ho, Wo, 32, needs_grad=False)
+
+    def conv_bn(self, ck, bk, x: Act, cout, ks, stride, relu, patch=False) -> Act:
+        st = self.store
+        real_ci = 3 if patch else x.C
+        ci = ConvInfo(ck, cout, real_ci, ks, stride, patch, st.param_off[ck + ".weight"], Cik=x.C)
+        kks, kstride = (1, 1) if patch else (ks, stride)
+        pad = 1 if kks == 3 else 0
+        Ho, Wo = (x.H + 2 * pad - kks) // kstride + 1, (x.W + 2 * pad - kks) // kstride + 1
+        # kernel-layout weights: forward [Co][taps][Cik]; data-gradient [Cik][taps][Co]
+        ci.fwd_off = self._wk_elems
+        self._wk_elems += cout * kks * kks * x.C
+        if x.needs_grad and self.training:
+            ci.bwd_off = self._wk_elems
+            self._wk_elems += cout * kks * kks * x.C
+        self.convs.append(ci)
+        bn = BNInfo(len(self.bns), cout, st.param_off[bk + ".weight"], st.buf_off[bk + ".running_mean"],
+                    self._stats_used, 1.0 / float(x.B * Ho * Wo))
+        self._stats_used += capi.NSHARD * 2 * cout
+        self.bns.append(bn)
+        y = Act("bn", self._act_tensor(x.B, Ho, Wo, cout), x.B, Ho, Wo, cout, bn=bn, relu=relu)
+        p = capi.Conv()
+        p.dtype = self.dtype
+        p.B, p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.Co = x.B, x.H, x.W, x.C, Ho, Wo, cout
+        p.ks, p.stride, p.stuff = kks, kstride, 0
+        p.TH, p.TW = choose_tile(x.B, Ho, Wo, kstride, kks, self.esz)
+        p.src = self._src(x)
+        p.out = y.ptr
+        if self.training:
+            p.out_stats = self.stats.data_ptr() + 8 * bn.stats_off
+        self._wk_fix.append((p, "w", ci.fwd_off))
+        self.fwd_ops.append(("stl_conv_forward", (p,)))
+        x.consumers += 1
+        self.tape.append(("conv", x, y, ci, (kks, kstride)))
+        return y
+
+    def fuse(self, terms, relu) -> Act:
+        terms = [(a, s, a.relu if a.kind == "bn" else False) for a, s in terms]
+        if len(terms) == 1 and terms[0][2] and not relu:
+            relu, terms = True, [(terms[0][0], terms[0][1], False)]  # relu(bn(y)) == fuse-level ReLU
+        assert not any(tr for _, _, tr in terms), "ReLU inside a multi-term sum is not part of this network"
+        base = [a for a, s, _ in terms if s == 0][0]
+        B, H, W, Cc = base.B, base.H, base.W, base.C
+        z = Act("plain", self._act_tensor(B, H, W, Cc), B, H, W, Cc)
+        p = capi.Fuse()
+        p.dtype, p.B, p.H, p.W, p.C, p.nterms, p.relu = self.dtype, B, H, W, Cc, len(terms), int(relu)
+        for i, (a, s, tr) in enumerate(terms):
+            assert a.C == Cc and a.H << s == H and a.W << s == W, "fuse: term shape mismatch"
+            p.t[i].src = self._src(a, relu=tr)
+            p.t[i].shift = s
+            a.consumers += 1
+        p.out = z.ptr
+        self.fwd_ops.append(("stl_fuse_forward", (p,)))
+        self.tape.append(("fuse", terms, z, relu))
+        return z
+
+    def head(self, key, x: Act, joints) -> torch.Tensor:
+        st = self.store
+        self.out = torch.zeros(x.B, joints, x.H, x.W, dtype=torch.float32, device=self.dev)
+        self.head_w = st.master.data_ptr() + 4 * st.param_off[key + ".weight"]
+        self.head_b = st.master.data_ptr() + 4 * st.param_off[key + ".bias"]
+        self.fwd_ops.append(("stl_head_forward", (self.dtype, x.ptr, self.head_w, self.head_b, self.out.data_ptr(),
+                                                  x.B, x.H, x.W, x.C, joints)))
+        x.consumers += 1
+        self.tape.append(("head", x, key, joints))
+        return self.out
+
+    # ------------------------------------------------------------------ weights in kernel layout
+    def _finalize_weights(self):
+        self.wk = torch.zeros(max(self._wk_elems, 1), dtype=self.tdtype, device=self.dev)
+        base = self.wk.data_ptr()
+        for p, attr, off in self._wk_fix:
+            setattr(p, attr, base + off * self.esz)
+        tab = (capi.WPrep * len(self.convs))()
+        blk = 0
+        for i, c in enumerate(self.convs):
+            e = tab[i]
+            e.src_off, e.fwd_off, e.bwd_off = c.master_off, c.fwd_off, c.bwd_off
+            e.Co, e.Ci, e.ks, e.Cip, e.patch, e.blk0 = c.Co, c.Ci, c.ks, c.Cik, int(c.patch), blk
+            blk += math.ceil(c.Co * c.Ci * c.ks * c.ks / 1024)
+        self._wprep_blocks = blk
+        self._wprep_tab = _to_device(tab, self.dev)
+        self._wprep_n = len(self.convs)
+
+    # ------------------------------------------------------------------ backward program
+    def _new_grad(self, a: Act) -> torch.Tensor:
+        return self._act_tensor(a.B, a.H, a.W, a.C)
+
+    def _build_backward(self):
+        st = self.store
+        ops = self.bwd_ops
+        self.slabs: List[Tuple] = []  # (struct_or_None, nelem, entry dict)
+        self._slab_elems = 0
+        J = self.out.shape[1]
+        self.dout = torch.zeros_like(self.out)
+        for node in reversed(self.tape):
+            kind = node[0]
+            if kind == "head":
+                _, x, key, joints = node
+                nblk = 256
+                dx = self._new_grad(x)
+                nel = joints * x.C + joints
+                part_off = self._slab_elems
+                self._slab_elems += nblk * nel
+                args = [self.dtype, x.ptr, self.head_w, self.dout.data_ptr(), dx.data_ptr(), None, nblk,
+                        x.B, x.H, x.W, x.C, joints]
+                self._head_bwd_args = (args, part_off)
+                ops.append(("stl_head_backward", args))
+                x.grads.append(dx)
+                self.slabs.append(dict(part_off=part_off, grad_off=st.param_off[key + ".weight"], nsplit=nblk,
+                                       Co=joints, Ci=x.C, ks=1, Cip=x.C, patch=0, stride=nel))
+                self.slabs.append(dict(part_off=part_off + joints * x.C, grad_off=st.param_off[key + ".bias"],
+                                       nsplit=nblk, Co=joints, Ci=1, ks=1, Cip=1, patch=0, stride=nel))
+            elif kind == "fuse":
+                _, terms, z, relu = node
+                assert 1 <= len(z.grads) <= 4, f"fuse output has {len(z.grads)} gradient contributions"
+                p = capi.FuseBwd()
+                p.dtype, p.B, p.H, p.W, p.C = self.dtype, z.B, z.H, z.W, z.C
+                p.ngrads, p.relu = len(z.grads), int(relu)
+                for i, gt in enumerate(z.grads):
+                    p.dz[i] = gt.data_ptr()
+                p.z = z.ptr
+                same_bn = [a for a, s, _ in terms if a.kind == "bn" and s == 0]
+                p.nbn = len(same_bn)
+                for i, a in enumerate(same_bn):
+                    p.bn[i] = self._src(a)
+                    p.rstats[i] = self.rstats.data_ptr() + 8 * a.bn.stats_off
+                trivial = (len(z.grads) == 1 and not relu and not same_bn)
+                du = z.grads[0] if trivial else self._new_grad(z)
+                p.du = du.data_ptr()
+                if not trivial:
+                    ops.append(("stl_fuse_backward", (p,)))
+                for a, s, _ in terms:
+                    if a.kind == "plain":
+                        assert s == 0, "upsampled plain terms do not occur in this network"
+                        if a.needs_grad:
+                            a.grads.append(du)
+                    elif s == 0:
+                        a.dt = du
+                    else:
+                        u = capi.UpBwd()
+                        u.dtype, u.B, u.H, u.W, u.C, u.shift = self.dtype, a.B, a.H, a.W, a.C, s
+                        u.du = du.data_ptr()
+                        a.dt = self._new_grad(a)
+                        u.dt = a.dt.data_ptr()
+                        u.bn = self._src(a)
+                        u.rstats = self.rstats.data_ptr() + 8 * a.bn.stats_off
+                        ops.append(("stl_upsample_backward", (u,)))
+            else:  # conv
+                _, x, y, ci, (kks, kstride) = node
+                assert y.consumers == 1 and y.dt is not None, f"{ci.key}: BN activation must have exactly one consumer"
+                g = self._gsrc(y)
+                # ---- weight gradient
+                wg = capi.Wgrad()
+                wg.dtype = self.dtype
+                wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = x.B, x.H, x.W, x.C, y.H, y.W, y.C
+                wg.ks, wg.stride = kks, kstride
+                wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32)
+                npt = math.ceil(x.B * (y.H + 1) / wg.TH) * math.ceil(y.W / wg.TW)
+                chunks = math.ceil(y.C / 32) * math.ceil(x.C / 32)
+                wg.nsplit = max(1, min(npt, 256 // chunks if chunks <= 256 else 1))
+                wg.h = self._src(x)
+                wg.g = g
+                nel = y.C * kks * kks * x.C
+                part_off = self._slab_elems
+                self._slab_elems += wg.nsplit * nel
+                self.slabs.append(dict(part_off=part_off, grad_off=ci.master_off, nsplit=wg.nsplit, Co=ci.Co, Ci=ci.Ci,
+                                       ks=ci.ks, Cip=ci.Cik, patch=int(ci.patch), stride=0, struct=wg))
+                ops.append(("stl_conv_wgrad", (wg,)))
+                # ---- data gradient
+                if not x.needs_grad:
+                    continue
+                d = capi.Conv()
+                d.dtype = self.dtype
+                d.B, d.Hi, d.Wi, d.Ci = y.B, y.H, y.W, y.C
+                d.Ho, d.Wo, d.Co = x.H, x.W, x.C
+                d.ks, d.stride, d.stuff = kks, 1, int(kstride == 2)
+                d.TH, d.TW = choose_tile(x.B, x.H, x.W, 1, kks, self.esz)
+                d.src = g
+                d.w = self.wk.data_ptr() + ci.bwd_off * self.esz
+                if x.kind == "plain":
+                    out = self._new_grad(x)
+                    if x.grads:
+                        d.addend = x.grads.pop().data_ptr()
+                    x.grads.append(out)
+                else:
+                    assert x.dt is None
+                    out = self._new_grad(x)
+                    x.dt = out
+                    d.mask_y = x.ptr
+                    d.mask_bn = self._src(x)
+                    d.red = self.rstats.data_ptr() + 8 * x.bn.stats_off
+                d.out = out.data_ptr()
+                ops.append(("stl_conv_forward", (d,)))
+        # slab arena + reduce table
+        self.slab_arena = torch.empty(max(self._slab_elems, 1), dtype=torch.float32, device=self.dev)
+        base = self.slab_arena.data_ptr()
+        args, off = self._head_bwd_args
+        args[5] = base + 4 * off
+        for s in self.slabs:
+            if "struct" in s:
+                s["struct"].partial = base + 4 * s["part_off"]
+        tab = (capi.Slab * len(self.slabs))()
+        blk = 0
+        for i, s in enumerate(self.slabs):
+            e = tab[i]
+            e.part_off, e.grad_off, e.nsplit = s["part_off"], s["grad_off"], s["nsplit"]
+            e.Co, e.Ci, e.ks, e.Cip, e.patch, e.blk0, e.pad = s["Co"], s["Ci"], s["ks"], s["Cip"], s["patch"], blk, s["stride"]
+            blk += math.ceil(s["Co"] * s["Ci"] * s["ks"] * s["ks"] / 1024)
+        self._slab_blocks, self._slab_n = blk, len(self.slabs)
+        self._slab_tab = _to_device(tab, self.dev)
+        self.bwd_ops = [(n, tuple(a)) for n, a in ops]
+
+    def _build_tables(self):
+        tab = (capi.BNRec * len(self.bns))()
+        for i, b in enumerate(self.bns):
+            e = tab[i]
+            e.stats_off, e.param_off, e.buf_off, e.C, e.inv_count = b.stats_off, b.param_off, b.buf_off, b.C, b.inv_count
+        self._bn_tab = _to_device(tab, self.dev)
+        # num_batches_tracked entries are in registry (state_dict) order == self.bns order
+        assert len(self.bns) == self.store.nnbt
+
+    # ------------------------------------------------------------------ execution
+    def _run(self, ops, stream: int):
+        lib = self.lib
+        for name, args in ops:
+            rc = getattr(lib, name)(*args, stream)
+            if rc != 0:
+                raise RuntimeError(f"{name}: {lib.stl_last_error().decode()}")
+
+    def prep_weights(self, stream: int):
+        st = self.store
+        capi.call("stl_weight_prep", self.dtype, st.master.data_ptr(), self.wk.data_ptr(), self._wprep_tab.data_ptr(),
+                  self._wprep_n, self._wprep_blocks, stream)
+
+    def forward(self, stream: int, update_running: bool = True):
+        """weights -> kernel layout, zero statistics, forward program, running-stat update."""
+        self.prep_weights(stream)
+        if self.training:
+            self.stats.zero_()
+        self._run(self.fwd_ops, stream)
+        if self.training and update_running:
+            st = self.store
+            capi.call("stl_bn_running_update", self.stats.data_ptr(), st.bufs.data_ptr(), st.nbt.data_ptr(),
+                      self._bn_tab.data_ptr(), len(self.bns), MOMENTUM, stream)
+
+    def backward(self, stream: int):
+        """expects self.dout filled; leaves dL/dparam in store.grads (overwrites)."""
+        assert self.training
+        st = self.store
+        self.rstats.zero_()
+        self._run(self.bwd_ops, stream)
+        capi.call("stl_bn_param_grads", self.rstats.data_ptr(), st.grads.data_ptr(), self._bn_tab.data_ptr(), len(self.bns), stream)
+        capi.call("stl_reduce_slabs", self.slab_arena.data_ptr(), st.grads.data_ptr(), self._slab_tab.data_ptr(),
+                  self._slab_n, self._slab_blocks, stream)
+
+
+def _is_bn_weight(key: str, reg: Registry) -> bool:
+    return key in _bn_weight_keys(reg)
+
+
+_bn_cache: Dict[int, set] = {}
+
+
+def _bn_weight_keys(reg: Registry) -> set:
+    s = _bn_cache.get(id(reg))
+    if s is None:
+        s = {k[: -len("running_mean")] + "weight" for k, _ in reg.buffers if k.endswith("running_mean")}
+        _bn_cache[id(reg)] = s
+    return s
+
+
+def _to_device(ctab, device) -> torch.Tensor:
+    raw = bytes(ctab)
+    t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone()
+    return t.to(device)

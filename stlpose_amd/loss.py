@@ -1,0 +1,66 @@
+"""Losses of the hot path on MI355X (mirror of reference ``src/lib/loss.py``)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import capi
+
+
+class _MSEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, output, target, target_weight):
+        if not output.is_cuda:
+            raise RuntimeError("PersonMSELoss (HIP) needs device tensors; there is no CPU path")
+        o = output.contiguous().float()
+        t = target.to(o.device).contiguous().float()
+        b, j = o.shape[:2]
+        hw = o[0, 0].numel()
+        w = target_weight.to(o.device).float().reshape(b, j).contiguous()
+        dout = torch.empty_like(o)
+        nblk = 256
+        partial = torch.empty(nblk, dtype=torch.float64, device=o.device)
+        loss = torch.empty((), dtype=torch.float32, device=o.device)
+        capi.call("stl_mse_loss", o.data_ptr(), t.data_ptr(), w.data_ptr(), dout.data_ptr(), partial.data_ptr(), nblk,
+                  loss.data_ptr(), b, j, hw, 1.0, torch.cuda.current_stream().cuda_stream)
+        ctx.save_for_backward(dout)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dout,) = ctx.saved_tensors
+        return dout * g, None, None
+
+
+class PersonMSELoss(nn.Module):
+    """reference lib/loss.py:61-94: mean over joints of 0.5 * MSE(o_j * w_j, t_j * w_j), i.e.
+    0.5 * mean(((o - t) * w)^2) over all B*J*H*W elements -- one fused HIP kernel that also
+    produces d(loss)/d(output)."""
+
+    def __init__(self, use_target_weight=1):
+        super().__init__()
+        self.use_target_weight = use_target_weight
+
+    def forward(self, output, target, target_weight=1):
+        if not torch.is_tensor(target_weight):
+            target_weight = torch.ones(output.shape[0], output.shape[1], 1, device=output.device)
+        return _MSEFn.apply(output, target, target_weight)
+
+
+def apply_perceptual_loss(exp_data, params, loss, perceptual_loss):
+    """reference lib/loss.py:97-150 (scalar re-weighting; same control flow and error behaviour)."""
+    use = False
+    if "perceptual_loss" not in exp_data["training"]:
+        exp_data["training"]["perceptual_loss"] = False
+    if getattr(params, "use_perceptual_loss", False) or exp_data["training"]["perceptual_loss"]:
+        use = True
+    if exp_data["dataset"]["dataset_name"] != "styled_coco" or use is False:
+        return loss
+    mean_perc = torch.mean(perceptual_loss).float().to(loss.device)
+    if exp_data["training"].get("lambda_D") is not None and exp_data["training"].get("lambda_P") is not None:
+        return loss * float(exp_data["training"]["lambda_D"]) + mean_perc * float(exp_data["training"]["lambda_P"])
+    if "perceptual_weight" not in exp_data["training"]:
+        exp_data["training"]["perceptual_weight"] = "add"
+    if exp_data["training"]["perceptual_weight"] == "add":
+        return loss + loss * mean_perc
+    raise SystemExit(f"ERROR! Weighting method '{exp_data['training']['perceptual_weight']}' is not supported")

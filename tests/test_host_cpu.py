@@ -1,0 +1,89 @@
+"""CPU: host logic -- the C-ABI library loads and exports every symbol the header declares, the
+drop-in module has the reference's state_dict ABI, and the static planner builds a consistent
+plan (no kernel is launched here)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from stlpose_amd import build
+    build.build(verbose=False)
+    from stlpose_amd import capi
+    return capi.lib()
+
+
+def test_capi_exports_every_declared_symbol(built_lib):
+    hdr = open(os.path.join(ROOT, "include", "stlpose_hip.h")).read()
+    declared = set(re.findall(r"\b(stl_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    from stlpose_amd import capi
+    for name in declared:
+        assert hasattr(built_lib, name), f"{name} declared in include/stlpose_hip.h but not exported"
+    assert set(capi.SIGNATURES) | {"stl_last_error"} == declared
+    assert built_lib.stl_version() == 1
+
+
+def test_struct_sizes_match_header(built_lib):
+    """ctypes mirrors must have the C layout (compile a tiny C program with gcc and compare sizeof)."""
+    import subprocess
+    import tempfile
+    from stlpose_amd import capi
+    src = '#include <stdio.h>\n#include "stlpose_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",' \
+          'sizeof(stl_src),sizeof(stl_conv),sizeof(stl_wgrad),sizeof(stl_term),sizeof(stl_fuse),sizeof(stl_fuse_bwd),' \
+          'sizeof(stl_upbwd),sizeof(stl_wprep),sizeof(stl_slab),sizeof(stl_bnrec));return 0;}'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        sizes = list(map(int, subprocess.check_output([os.path.join(d, "s")]).split()))
+    import ctypes
+    mine = [ctypes.sizeof(c) for c in (capi.Src, capi.Conv, capi.Wgrad, capi.Term, capi.Fuse, capi.FuseBwd, capi.UpBwd,
+                                       capi.WPrep, capi.Slab, capi.BNRec)]
+    assert mine == sizes
+
+
+def test_dropin_state_dict_abi(golden_dir):
+    from stlpose_amd import PoseHighResolutionNet
+    m = PoseHighResolutionNet(is_train=False)  # reference call site lib/model_setup.py:38
+    lines = [f"{k} {'x'.join(map(str, v.shape))}" for k, v in m.state_dict().items()]
+    assert lines == open(os.path.join(golden_dir, "g8_w32_keys.txt")).read().splitlines()
+    assert sum(p.numel() for p in m.parameters()) == 28536113
+    # strict load of an oracle (== reference-layout) checkpoint, with and without DataParallel's prefix
+    from oracle import hrnet_ref
+    ref = hrnet_ref.load_synth(hrnet_ref.RefPoseNet("w32"))
+    m.load_state_dict(ref.state_dict(), strict=True)
+    assert torch.equal(m.stage3[1].fuse_layers[2][0][1][0].weight, ref.stage3[1].fuse_layers[2][0][1][0].weight)
+    wrapped = torch.nn.DataParallel(m)
+    wrapped.load_state_dict({"module." + k: v for k, v in ref.state_dict().items()}, strict=True)
+    assert m.training and not m.eval().training
+    assert sum(p.numel() for p in PoseHighResolutionNet("w48").parameters()) == 63595745
+
+
+def test_planner_dry_run():
+    """Plan construction needs no GPU: check op counts against SURVEY 8(a) (293 convs incl. head,
+    28 upsample terms) and that every BN activation has a single consumer."""
+    from collections import Counter
+    from stlpose_amd import PoseHighResolutionNet, capi
+    from stlpose_amd.engine import Engine
+    m = PoseHighResolutionNet("w32", "bf16")
+    m._pack(torch.device("cpu"))
+    e = Engine(m.arch, m._store, 2, 256, 192, capi.BF16, True)
+    f, b = Counter(n for n, _ in e.fwd_ops), Counter(n for n, _ in e.bwd_ops)
+    assert f["stl_conv_forward"] + f["stl_head_forward"] == 293
+    assert b["stl_conv_wgrad"] == 292 and b["stl_conv_forward"] == 291 and b["stl_upsample_backward"] == 28
+    assert len(e.bns) == 292 and e.out.shape == (2, 17, 64, 48)
+    ev = Engine(m.arch, m._store, 1, 64, 64, capi.F32, False)
+    assert not ev.bwd_ops
+
+
+def test_choose_tile_bounds():
+    from stlpose_amd.engine import choose_tile
+    for (B, H, W, s, ks) in [(32, 96, 72, 1, 3), (32, 12, 9, 1, 3), (2, 8, 6, 1, 1), (32, 48, 36, 2, 3), (1, 3, 2, 1, 3)]:
+        th, tw = choose_tile(B, H, W, s, ks, 2)
+        assert 1 <= th and 1 <= tw <= W and th * tw <= 128

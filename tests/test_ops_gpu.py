@@ -1,0 +1,349 @@
+"""GPU: each HIP kernel through the C ABI against a plain PyTorch fp32 reference of the same op
+(tolerances: fp32 path 1e-4 relative to the tensor's max; bf16 path 2e-2)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from stlpose_amd import capi  # noqa: E402
+from stlpose_amd.engine import choose_tile  # noqa: E402
+
+DT = {"fp32": (capi.F32, torch.float32, 2e-4), "bf16": (capi.BF16, torch.bfloat16, 3e-2)}
+EPS = 1e-5
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def nhwc(x, td):
+    return x.permute(0, 2, 3, 1).contiguous().to(td)
+
+
+def from_nhwc(t, B, H, W, Cc):
+    return t.view(B, H, W, Cc).float().permute(0, 3, 1, 2).contiguous()
+
+
+def relerr(a, b):
+    return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-12))
+
+
+def stats_of(y_nhwc, Cc):
+    """[NSHARD][2C] fp64 sums as the conv epilogue would produce them (all in shard 0)."""
+    f = y_nhwc.float().reshape(-1, Cc).double()
+    st = torch.zeros(capi.NSHARD, 2, Cc, dtype=torch.float64, device=y_nhwc.device)
+    st[0, 0], st[0, 1] = f.sum(0), (f * f).sum(0)
+    return st
+
+
+def bn_src(xt, stats, gamma, beta, n, relu):
+    s = capi.Src()
+    s.x, s.mode, s.relu = xt.data_ptr(), capi.SRC_BN, int(relu)
+    s.stats, s.gamma, s.beta = stats.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    s.inv_count, s.eps = 1.0 / n, EPS
+    return s
+
+
+def test_selftest_lane_maps():
+    out = torch.full((4,), -1.0, device="cuda")
+    capi.call("stl_selftest_mfma", out.data_ptr(), stream())
+    torch.cuda.synchronize()
+    assert out.tolist() == [0.0, 0.0, 0.0, 0.0], f"bf16-mfma / f32-mfma / tr-read / f64-atomic errors: {out.tolist()}"
+
+
+CONV_CASES = [
+    # B, H, W, Ci, Co, ks, stride
+    (2, 24, 16, 32, 32, 3, 1),
+    (3, 12, 9, 64, 64, 3, 1),
+    (2, 24, 18, 32, 64, 3, 2),
+    (2, 8, 6, 256, 64, 1, 1),
+    (2, 16, 12, 48, 48, 3, 1),     # ragged channel chunk (W48 widths)
+    (1, 30, 22, 128, 32, 3, 1),    # odd tile edges
+    (2, 13, 11, 32, 32, 3, 2),     # odd input size, stride 2
+]
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_plain_and_stats(case, dt):
+    code, td, tol = DT[dt]
+    B, H, W, Ci, Co, ks, s = case
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(B, Ci, H, W, device="cuda", generator=g)
+    w = torch.randn(Co, Ci, ks, ks, device="cuda", generator=g) / math.sqrt(Ci * ks * ks)
+    xt, wt = nhwc(x, td), w.permute(0, 2, 3, 1).contiguous().to(td)
+    pad = 1 if ks == 3 else 0
+    ref = F.conv2d(xt.float().permute(0, 3, 1, 2), wt.float().permute(0, 3, 1, 2), stride=s, padding=pad)
+    Ho, Wo = ref.shape[2:]
+    out = torch.full((B * Ho * Wo * Co,), float("nan"), device="cuda", dtype=td)
+    st = torch.zeros(capi.NSHARD * 2 * Co, dtype=torch.float64, device="cuda")
+    p = capi.Conv()
+    p.dtype, p.B, p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.Co = code, B, H, W, Ci, Ho, Wo, Co
+    p.ks, p.stride = ks, s
+    p.TH, p.TW = choose_tile(B, Ho, Wo, s, ks, xt.element_size())
+    p.src.x, p.src.mode = xt.data_ptr(), capi.SRC_PLAIN
+    p.w, p.out, p.out_stats = wt.data_ptr(), out.data_ptr(), st.data_ptr()
+    capi.call("stl_conv_forward", C.byref(p), stream())
+    torch.cuda.synchronize()
+    got = from_nhwc(out, B, Ho, Wo, Co)
+    assert not torch.isnan(got).any()
+    assert relerr(got, ref) < tol
+    # statistics are those of the STORED tensor
+    sums = st.view(capi.NSHARD, 2, Co).sum(0)
+    stored = out.view(-1, Co).double()
+    assert torch.allclose(sums[0], stored.sum(0), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(sums[1], (stored * stored).sum(0), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 24, 16, 32, 32, 3, 1), (2, 24, 18, 32, 64, 3, 2), (2, 8, 6, 128, 64, 1, 1)])
+def test_conv_bn_relu_chain_forward_backward(case, dt):
+    """x --BN(relu) on load--> conv --> y ; backward: BN-backward on load, ReLU mask + r1/r2 in the
+    data-gradient epilogue, weight gradient slabs.  Reference: torch autograd through
+    batch_norm(train) -> relu -> conv2d -> batch_norm(train)."""
+    code, td, tol = DT[dt]
+    B, H, W, Ci, Co, ks, s = case
+    g = torch.Generator(device="cuda").manual_seed(2)
+    pad = 1 if ks == 3 else 0
+    x0 = torch.randn(B, Ci, H, W, device="cuda", generator=g) * 1.5 + 0.3
+    x0t = nhwc(x0, td)
+    x0r = x0t.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)  # the stored raw tensor
+    w = (torch.randn(Co, Ci, ks, ks, device="cuda", generator=g) / math.sqrt(Ci * ks * ks))
+    wt = w.permute(0, 2, 3, 1).contiguous().to(td)
+    wr = wt.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    g1 = (torch.rand(Ci, device="cuda", generator=g) + 0.5).requires_grad_(True)
+    b1 = (torch.rand(Ci, device="cuda", generator=g) - 0.5).requires_grad_(True)
+    g2 = (torch.rand(Co, device="cuda", generator=g) + 0.5).requires_grad_(True)
+    b2 = (torch.rand(Co, device="cuda", generator=g) - 0.5).requires_grad_(True)
+    h = F.relu(F.batch_norm(x0r, None, None, g1, b1, True, 0.1, EPS))
+    y = F.conv2d(h, wr, stride=s, padding=pad)
+    t = F.batch_norm(y, None, None, g2, b2, True, 0.1, EPS)
+    Ho, Wo = y.shape[2:]
+    dt_up = torch.randn(B, Co, Ho, Wo, device="cuda", generator=g)
+    dtt = nhwc(dt_up, td)
+    t.backward(dtt.float().permute(0, 3, 1, 2))
+    # ---------------- HIP forward
+    st1 = stats_of(x0t, Ci)
+    yk = torch.empty(B * Ho * Wo * Co, device="cuda", dtype=td)
+    st2 = torch.zeros(capi.NSHARD * 2 * Co, dtype=torch.float64, device="cuda")
+    p = capi.Conv()
+    p.dtype, p.B, p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.Co = code, B, H, W, Ci, Ho, Wo, Co
+    p.ks, p.stride = ks, s
+    p.TH, p.TW = choose_tile(B, Ho, Wo, s, ks, x0t.element_size())
+    p.src = bn_src(x0t, st1, g1.detach(), b1.detach(), B * H * W, True)
+    p.w, p.out, p.out_stats = wt.data_ptr(), yk.data_ptr(), st2.data_ptr()
+    capi.call("stl_conv_forward", C.byref(p), stream())
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc(yk, B, Ho, Wo, Co), y.detach()) < tol
+    # ---------------- backward reductions for BN2 (what fuse_backward would have produced)
+    ykf = yk.view(-1, Co).double()
+    mean2 = ykf.mean(0)
+    rstd2 = 1.0 / torch.sqrt(ykf.var(0, unbiased=False) + EPS)
+    dtf = dtt.view(-1, Co).double()
+    rst2 = torch.zeros(capi.NSHARD, 2, Co, dtype=torch.float64, device="cuda")
+    rst2[0, 0] = dtf.sum(0)
+    rst2[0, 1] = (dtf * (ykf - mean2) * rstd2).sum(0)
+    gs = capi.Src()
+    gs.x, gs.y, gs.mode = dtt.data_ptr(), yk.data_ptr(), capi.SRC_BNBWD
+    gs.stats, gs.rstats, gs.gamma = st2.data_ptr(), rst2.data_ptr(), g2.detach().data_ptr()
+    gs.inv_count, gs.eps = 1.0 / (B * Ho * Wo), EPS
+    # ---------------- weight gradient
+    wg = capi.Wgrad()
+    wg.dtype, wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = code, B, H, W, Ci, Ho, Wo, Co
+    wg.ks, wg.stride = ks, s
+    wg.TH, wg.TW = choose_tile(B, Ho, Wo, s, ks, x0t.element_size(), bn_cols=32)
+    wg.nsplit = 3
+    part = torch.full((3 * Co * ks * ks * Ci,), float("nan"), device="cuda")
+    wg.h, wg.g, wg.partial = p.src, gs, part.data_ptr()
+    capi.call("stl_conv_wgrad", C.byref(wg), stream())
+    torch.cuda.synchronize()
+    dw = part.view(3, Co, ks * ks, Ci).sum(0).view(Co, ks, ks, Ci).permute(0, 3, 1, 2)
+    assert not torch.isnan(dw).any()
+    assert relerr(dw, wr.grad) < tol * 3
+    # ---------------- data gradient with ReLU mask + BN1 reductions
+    wb = wt.float().view(Co, ks * ks, Ci).flip(1).permute(2, 1, 0).contiguous().to(td)  # [Ci][8-tap][Co]
+    dx = torch.full((B * H * W * Ci,), float("nan"), device="cuda", dtype=td)
+    red = torch.zeros(capi.NSHARD * 2 * Ci, dtype=torch.float64, device="cuda")
+    d = capi.Conv()
+    d.dtype, d.B, d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.Co = code, B, Ho, Wo, Co, H, W, Ci
+    d.ks, d.stride, d.stuff = ks, 1, int(s == 2)
+    d.TH, d.TW = choose_tile(B, H, W, 1, ks, x0t.element_size())
+    d.src, d.w, d.out = gs, wb.data_ptr(), dx.data_ptr()
+    d.mask_y, d.mask_bn, d.red = x0t.data_ptr(), p.src, red.data_ptr()
+    capi.call("stl_conv_forward", C.byref(d), stream())
+    torch.cuda.synchronize()
+    # reference for the masked gradient wrt the BN1 output: dL/dh * (h > 0)
+    x0f = x0t.float().view(-1, Ci).double()
+    mean1, rstd1 = x0f.mean(0), 1.0 / torch.sqrt(x0f.var(0, unbiased=False) + EPS)
+    xhat = (x0f - mean1) * rstd1
+    dxk = dx.view(-1, Ci).double()
+    assert not torch.isnan(dxk).any()
+    # dgamma1 = sum dt1 * xhat, dbeta1 = sum dt1 from torch
+    r = red.view(capi.NSHARD, 2, Ci).sum(0)
+    assert relerr(r[0], b1.grad.double()) < tol * 3
+    assert relerr(r[1], g1.grad.double()) < tol * 3
+    # full BN1 backward from the kernel's dt1 must reproduce dL/dx0
+    n = B * H * W
+    dx0 = (g1.detach().double() * rstd1) * (dxk - r[0] / n - xhat * r[1] / n)
+    ref = x0r.grad.permute(0, 2, 3, 1).reshape(-1, Ci).double()
+    assert relerr(dx0, ref) < tol * 3
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_fuse_forward_backward_upsample(dt):
+    code, td, tol = DT[dt]
+    B, H, W, Cc = 2, 16, 12, 32
+    g = torch.Generator(device="cuda").manual_seed(3)
+    xp = nhwc(torch.randn(B, Cc, H, W, device="cuda", generator=g), td)
+    y1 = nhwc(torch.randn(B, Cc, H, W, device="cuda", generator=g) * 2 + 1, td)
+    y2 = nhwc(torch.randn(B, Cc, H // 4, W // 4, device="cuda", generator=g), td)
+    ga = [torch.rand(Cc, device="cuda", generator=g) + 0.5 for _ in range(2)]
+    be = [torch.rand(Cc, device="cuda", generator=g) - 0.5 for _ in range(2)]
+    leaf = [t.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True) for t in (xp, y1, y2)]
+    t1 = F.batch_norm(leaf[1], None, None, ga[0], be[0], True, 0.1, EPS)
+    t2 = F.interpolate(F.batch_norm(leaf[2], None, None, ga[1], be[1], True, 0.1, EPS), scale_factor=4, mode="nearest")
+    z = F.relu(t1 + leaf[0] + t2)
+    s1, s2 = stats_of(y1, Cc), stats_of(y2, Cc)
+    p = capi.Fuse()
+    p.dtype, p.B, p.H, p.W, p.C, p.nterms, p.relu = code, B, H, W, Cc, 3, 1
+    p.t[0].src = bn_src(y1, s1, ga[0], be[0], B * H * W, False)
+    p.t[1].src.x, p.t[1].src.mode = xp.data_ptr(), capi.SRC_PLAIN
+    p.t[2].src = bn_src(y2, s2, ga[1], be[1], B * (H // 4) * (W // 4), False)
+    p.t[2].shift = 2
+    zk = torch.empty(B * H * W * Cc, device="cuda", dtype=td)
+    p.out = zk.data_ptr()
+    capi.call("stl_fuse_forward", C.byref(p), stream())
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc(zk, B, H, W, Cc), z.detach()) < tol
+    # backward with two gradient contributions
+    d1 = nhwc(torch.randn(B, Cc, H, W, device="cuda", generator=g), td)
+    d2 = nhwc(torch.randn(B, Cc, H, W, device="cuda", generator=g), td)
+    zs = zk.view(B, H, W, Cc).float().permute(0, 3, 1, 2)
+    dsum = (d1.float() + d2.float()).permute(0, 3, 1, 2)
+    z.backward(dsum)
+    q = capi.FuseBwd()
+    q.dtype, q.B, q.H, q.W, q.C, q.ngrads, q.relu, q.nbn = code, B, H, W, Cc, 2, 1, 1
+    q.dz[0], q.dz[1], q.z = d1.data_ptr(), d2.data_ptr(), zk.data_ptr()
+    du = torch.empty_like(zk)
+    q.du = du.data_ptr()
+    q.bn[0] = p.t[0].src
+    r1 = torch.zeros(capi.NSHARD * 2 * Cc, dtype=torch.float64, device="cuda")
+    q.rstats[0] = r1.data_ptr()
+    capi.call("stl_fuse_backward", C.byref(q), stream())
+    u = capi.UpBwd()
+    u.dtype, u.B, u.H, u.W, u.C, u.shift = code, B, H // 4, W // 4, Cc, 2
+    dtl = torch.empty(B * (H // 4) * (W // 4) * Cc, device="cuda", dtype=td)
+    r2 = torch.zeros(capi.NSHARD * 2 * Cc, dtype=torch.float64, device="cuda")
+    u.du, u.dt, u.bn, u.rstats = du.data_ptr(), dtl.data_ptr(), p.t[2].src, r2.data_ptr()
+    capi.call("stl_upsample_backward", C.byref(u), stream())
+    torch.cuda.synchronize()
+    du_ref = dsum * (zs > 0)
+    assert relerr(from_nhwc(du, B, H, W, Cc), du_ref) < tol          # also d/d(plain x)
+    assert relerr(from_nhwc(du, B, H, W, Cc), leaf[0].grad) < tol
+    # BN term reductions -> full BN backward == autograd's dL/dy
+    for yt, st_, rr, gam, lf, dtk, n in ((y1, s1, r1, ga[0], leaf[1], du, B * H * W),
+                                         (y2, s2, r2, ga[1], leaf[2], dtl, B * (H // 4) * (W // 4))):
+        yf = yt.view(-1, Cc).double()
+        mean, rstd = yf.mean(0), 1.0 / torch.sqrt(yf.var(0, unbiased=False) + EPS)
+        r = rr.view(capi.NSHARD, 2, Cc).sum(0)
+        dy = (gam.double() * rstd) * (dtk.view(-1, Cc).double() - r[0] / n - (yf - mean) * rstd * r[1] / n)
+        ref = lf.grad.permute(0, 2, 3, 1).reshape(-1, Cc).double()
+        assert relerr(dy, ref) < tol * 3
+
+
+def test_head_mse_argmax_golden(golden_dir):
+    import os
+    g6 = np.load(os.path.join(golden_dir, "g6_mse.npz"))
+    for name in ("b4", "b1"):
+        o = torch.from_numpy(g6[f"{name}_o"]).cuda().requires_grad_(True)
+        from stlpose_amd.loss import PersonMSELoss
+        l = PersonMSELoss()(o, torch.from_numpy(g6[f"{name}_t"]).cuda(), torch.from_numpy(g6[f"{name}_w"]).cuda())
+        l.backward()
+        assert abs(l.item() - float(g6[f"{name}_loss"])) < 1e-5 * abs(float(g6[f"{name}_loss"]))
+        np.testing.assert_allclose(o.grad.cpu().numpy(), g6[f"{name}_grad"], rtol=1e-4, atol=1e-9)
+    g7 = np.load(os.path.join(golden_dir, "g7_decode.npz"))
+    from stlpose_amd import pose_parsing
+    p, mv = pose_parsing.get_max_preds_hrnet(g7["hm"])
+    assert np.array_equal(p, g7["preds"]) and np.array_equal(mv, g7["maxvals"])   # bit-exact incl. ties
+    assert pose_parsing.get_max_preds_hrnet(np.zeros((0, 17, 4, 4), np.float32)) == ([], [])
+    fp, fmv, coords = pose_parsing.get_final_preds_hrnet(g7["hm"], g7["center"], g7["scale"])
+    np.testing.assert_allclose(fp, g7["final_preds"], rtol=1e-5, atol=2e-3)
+    np.testing.assert_allclose(coords, g7["final_coords"], atol=1e-3)
+    # flip_merge == 0.5 * (a + shift(flip_back(b)))
+    a = torch.randn(3, 17, 16, 12, device="cuda")
+    hm = torch.from_numpy(g7["hm"]).cuda()
+    from stlpose_amd.inference import _perm
+    out = torch.empty_like(a)
+    capi.call("stl_flip_merge", a.data_ptr(), hm.data_ptr(), out.data_ptr(), _perm(17, "cuda").data_ptr(), 3, 17, 16, 12, stream())
+    fb = torch.from_numpy(g7["flip_back"]).cuda()
+    sh = fb.clone()
+    sh[..., 1:] = fb[..., :-1]
+    assert torch.allclose(out, 0.5 * (a + sh), atol=1e-6)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_head_forward_backward(dt):
+    code, td, tol = DT[dt]
+    B, H, W, Ci, J = 2, 24, 16, 32, 17
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = nhwc(torch.randn(B, Ci, H, W, device="cuda", generator=g), td)
+    w = (torch.randn(J, Ci, 1, 1, device="cuda", generator=g) * 0.2).requires_grad_(True)
+    b = torch.randn(J, device="cuda", generator=g).requires_grad_(True)
+    xr = x.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    ref = F.conv2d(xr, w, b)
+    out = torch.empty(B, J, H, W, device="cuda")
+    capi.call("stl_head_forward", code, x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), B, H, W, Ci, J, stream())
+    torch.cuda.synchronize()
+    assert relerr(out, ref.detach()) < 1e-5
+    do = torch.randn(B, J, H, W, device="cuda", generator=g)
+    ref.backward(do)
+    nblk, nel = 7, J * Ci + J
+    dx = torch.empty(B * H * W * Ci, device="cuda", dtype=td)
+    part = torch.full((nblk * nel,), float("nan"), device="cuda")
+    capi.call("stl_head_backward", code, x.data_ptr(), w.data_ptr(), do.data_ptr(), dx.data_ptr(), part.data_ptr(), nblk,
+              B, H, W, Ci, J, stream())
+    torch.cuda.synchronize()
+    s = part.view(nblk, nel).sum(0)
+    assert relerr(from_nhwc(dx, B, H, W, Ci), xr.grad) < tol
+    assert relerr(s[: J * Ci].view(J, Ci), w.grad.view(J, Ci)) < 1e-4
+    assert relerr(s[J * Ci:], b.grad) < 1e-4
+
+
+def test_optimizers_match_torch():
+    n = 10007
+    g = torch.Generator(device="cuda").manual_seed(7)
+    p0 = torch.randn(n, device="cuda", generator=g)
+    for kind in ("adam", "sgd"):
+        pk = p0.clone()
+        pt = p0.clone().requires_grad_(True)
+        if kind == "adam":
+            opt = torch.optim.Adam([pt], lr=1e-3)
+            hyper = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 0.0, 0.0, 0.0, 1.0], device="cuda")
+        else:
+            opt = torch.optim.SGD([pt], lr=1e-2, momentum=0.9, nesterov=True, weight_decay=5e-4)
+            hyper = torch.tensor([1e-2, 0.0, 0.0, 0.0, 5e-4, 0.9, 1.0, 1.0], device="cuda")
+        m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        step = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for it in range(3):
+            gr = torch.randn(n, device="cuda", generator=g)
+            pt.grad = gr.clone()
+            opt.step()
+            if kind == "adam":
+                capi.call("stl_adam_step", pk.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), n, hyper.data_ptr(), step.data_ptr(), stream())
+            else:
+                capi.call("stl_sgd_step", pk.data_ptr(), gr.data_ptr(), m.data_ptr(), n, hyper.data_ptr(), step.data_ptr(), stream())
+        torch.cuda.synchronize()
+        assert int(step.item()) == 3
+        assert torch.allclose(pk, pt.detach(), rtol=1e-5, atol=1e-6), kind
+
+
+def test_error_reporting():
+    p = capi.Conv()
+    p.dtype, p.ks, p.stride = 0, 5, 1
+    with pytest.raises(RuntimeError, match="ks must be 1 or 3"):
+        capi.call("stl_conv_forward", C.byref(p), stream())
