@@ -244,7 +244,7 @@ extern "C" int stl_conv_wgrad(const stl_wgrad* pp, void* stream) {
     k.psg = k.psh = 32 * esz + 16;
     k.off_cg = 0;
     k.off_ch = 3 * 32 * 4;
-    k.off_g = 512;
+    k.off_g = 1024;  // consts: g [3][32] floats at 0, h [2][32] floats at 384 -> 640 B used
     int szG = 128 * k.psg;
     const int szRed = 4 * k.taps * 256 * 4;
     int szH = k.HP * k.psh;
