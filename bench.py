@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one HRNet-W32 384x288 train step (BASELINE.json configs[1]):
+fwd + masked-MSE + bwd + Adam (+ RCCL gradient all-reduce when N > 1), bf16 storage / fp32
+accumulate, batch 32 per GPU, synthetic inputs already resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W
+(N > 1: launched by torch.distributed.run, one rank per GPU.)  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOPS_PER_IMG = {("w32", 384, 288): 103.11e9, ("w32", 256, 192): 45.83e9, ("w48", 384, 288): 211.74e9,
+                 ("w48", 256, 192): 94.11e9}  # fwd + dgrad + wgrad, convs only
+MFMA_PEAK_BF16 = 2500.0  # TFLOP/s dense (MI355X_MICROARCH.md)
+HBM_PEAK = 8000.0        # GB/s
+
+
+def synth_batch(B, H, W, rank, device, sigma=3.0, joints=17):
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    img = torch.randn(B, 3, H, W, generator=g)
+    hh, ww = H // 4, W // 4
+    cx = torch.randint(0, ww, (B, joints, 1, 1), generator=g).float()
+    cy = torch.randint(0, hh, (B, joints, 1, 1), generator=g).float()
+    ys = torch.arange(hh).view(1, 1, hh, 1).float()
+    xs = torch.arange(ww).view(1, 1, 1, ww).float()
+    tgt = torch.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) / (2 * sigma ** 2))
+    tw = (torch.rand(B, joints, 1, generator=g) < 0.8).float()
+    return img.to(device), tgt.to(device), tw.to(device)
+
+
+def time_dominant_kernel(ts, reps=40):
+    """Average launch duration of the dominant kernel class (3x3 stride-1 C->C conv of the
+    highest-resolution branch: 64 launches fwd + 64 dgrad per step), HIP events on the launch stream."""
+    from stlpose_amd import capi
+    eng = ts.eng
+    cand = None
+    for name, args, *_ in eng.fwd_ops:
+        if name == "stl_conv_forward":
+            p = args[0]
+            if p.ks == 3 and p.stride == 1 and p.Ci == p.Co and p.Ho == eng.H // 4 and p.src.mode == capi.SRC_BN:
+                cand = p
+                break
+    if cand is None:
+        return None
+    st = torch.cuda.current_stream().cuda_stream
+    lib = capi.lib()
+    for _ in range(5):
+        lib.stl_conv_forward(C.byref(cand), st)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        lib.stl_conv_forward(C.byref(cand), st)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    px = cand.B * cand.Ho * cand.Wo
+    flops = 2.0 * px * cand.Co * cand.Ci * 9
+    esz = 2 if cand.dtype == capi.BF16 else 4
+    bytes_alg = px * (cand.Ci + cand.Co) * esz + cand.Co * cand.Ci * 9 * esz
+    return dict(kernel="conv_core<bf16,3x3,BN=32> C32 96x72 (BN+ReLU on load, stats epilogue)", ms=ms,
+                tflops=flops / ms / 1e9, gbs=bytes_alg / ms / 1e6, flops=flops, bytes=bytes_alg)
+
+
+def cpu_baseline(arch, H, W, seconds=20.0):
+    """The oracle (plain torch fp32 restatement of the reference graph) timed on the host cores."""
+    from oracle import hrnet_ref, pose_ref
+    torch.manual_seed(0)
+    B = 4
+    m = hrnet_ref.RefPoseNet(arch).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    img = torch.randn(B, 3, H, W)
+    tgt = torch.rand(B, 17, H // 4, W // 4)
+    tw = torch.ones(B, 17, 1)
+    times = []
+    t_end = time.time() + seconds
+    while time.time() < t_end or len(times) < 2:
+        t0 = time.time()
+        opt.zero_grad()
+        loss = pose_ref.person_mse_loss(m(img), tgt, tw)
+        loss.backward()
+        opt.step()
+        times.append(time.time() - t0)
+        if len(times) >= 12:
+            break
+    med = float(np.median(times[1:])) if len(times) > 1 else times[0]
+    return dict(value=B / med, unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle RefPoseNet({arch}) fp32 {H}x{W} bs{B} fwd+MSE+bwd+Adam, median of {max(len(times) - 1, 1)} steps")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--arch", default="w32")
+    ap.add_argument("--height", type=int, default=384)
+    ap.add_argument("--width", type=int, default=288)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        pg = dist.group.WORLD
+
+    from stlpose_amd import PoseHighResolutionNet
+    from stlpose_amd.train_step import TrainStep
+    torch.manual_seed(0)  # identical random-init weights on every rank
+    model = PoseHighResolutionNet(a.arch, a.dtype).to(dev)
+    ts = TrainStep(model, a.batch, a.height, a.width, optimizer="adam", lr=1e-3, process_group=pg,
+                   use_graph=not a.no_graph, device=dev)
+    img, tgt, tw = synth_batch(a.batch, a.height, a.width, rank, dev, sigma=3.0 if a.height >= 384 else 2.0)
+    ts.load_batch(img, tgt, tw)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        ts.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ts.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    loss = float(ts.loss.item())
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / a.steps * 1e3
+    value = a.batch * world * a.steps / dt
+
+    if rank == 0:
+        flops_img = FLOPS_PER_IMG.get((a.arch, a.height, a.width))
+        dom = time_dominant_kernel(ts)
+        roof = None
+        if dom:
+            roof = dict(bound="mfma", achieved=round(dom["tflops"], 2), peak=MFMA_PEAK_BF16, unit="TFLOP/s",
+                        frac=round(dom["tflops"] / MFMA_PEAK_BF16, 4), traffic=None, kernel=dom["kernel"],
+                        launch_ms=round(dom["ms"], 5), algorithmic_GBps=round(dom["gbs"], 1),
+                        hbm_frac=round(dom["gbs"] / HBM_PEAK, 4))
+        out = dict(metric="images/sec/GPU HRNet-W32 384x288 train step; PCKh@0.5 parity", value=round(value, 2),
+                   unit="images/sec", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.dtype, data="synthetic",
+                   config=dict(workload=f"HRNet-{a.arch.upper()} {a.height}x{a.width} bs={a.batch}/GPU train step "
+                                        f"(fwd+MSE+bwd+Adam{'+RCCL allreduce' if world > 1 else ''}), random-init weights",
+                               global_batch=a.batch * world, parallelism=f"dp{world}"),
+                   loss=loss,
+                   step_tflops=round(value * flops_img / 1e12, 2) if flops_img else None,
+                   step_mfma_frac=round(value / world * flops_img / 1e12 / MFMA_PEAK_BF16, 4) if flops_img else None,
+                   roofline=roof)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.arch, a.height, a.width)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

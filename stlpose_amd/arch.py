@@ -35,6 +35,7 @@ def walk(g, a: Arch):
       g.conv_bn(conv_key, bn_key, x, cout, ks, stride, relu, patch=False) -> act (BN on load)
       g.fuse(terms=[(act, log2_upsample)], relu)      -> act  (materialised)
       g.head(key, x, joints)                          -> output
+      g.set_stream(i)                                 scheduling hint: following ops go to HIP stream i
     Call order == reference registration order, so the registry comes out in state_dict order.
     """
     w = a.widths
@@ -62,8 +63,10 @@ def walk(g, a: Arch):
             ys = _exchange_module(g, f"stage{stage}.{m}", ys, w[:nbr], a.blocks, full)
         if stage < 4:  # transition to the next stage: new branch from the LAST branch (:451-463)
             key = f"transition{stage}.{nbr}.0"
+            g.set_stream(nbr)
             t = g.conv_bn(f"{key}.0", f"{key}.1", ys[-1], w[nbr], 3, 2, True)
             ys = ys + [g.fuse([(t, 0)], relu=False)]
+            g.set_stream(0)
     return g.head("final_layer", ys[0], a.joints)
 
 
@@ -72,6 +75,7 @@ def _exchange_module(g, p: str, xs: List, widths: Sequence[int], nblocks: int, f
     n = len(widths)
     xs = list(xs)
     for b in range(n):
+        g.set_stream(b)  # branches are independent until the exchange -> one HIP stream each
         x = xs[b]
         for k in range(nblocks):
             q = f"{p}.branches.{b}.{k}"
@@ -81,6 +85,7 @@ def _exchange_module(g, p: str, xs: List, widths: Sequence[int], nblocks: int, f
         xs[b] = x
     outs = []
     for i in range(n if full else 1):
+        g.set_stream(i)
         terms = []
         for j in range(n):
             q = f"{p}.fuse_layers.{i}.{j}"
@@ -95,6 +100,7 @@ def _exchange_module(g, p: str, xs: List, widths: Sequence[int], nblocks: int, f
                     t = g.conv_bn(f"{q}.{k}.0", f"{q}.{k}.1", t, widths[i] if last else widths[j], 3, 2, not last)
                 terms.append((t, 0))
         outs.append(g.fuse(terms, relu=True))
+    g.set_stream(0)
     return outs
 
 
@@ -123,6 +129,9 @@ class _RegistryBuilder:
 
     def stem_input(self):
         return 3
+
+    def set_stream(self, s):
+        pass
 
     def conv_bn(self, ck, bk, x, cout, ks, stride, relu, patch=False):
         cin = x

@@ -7,6 +7,10 @@
 //   Block = 256 threads = 4 waves; wave w owns row tiles {2w, 2w+1} x all BN/16 column tiles.
 //   Pixel tiles are taken from "virtual rows": the batch is stacked along y with one zero row
 //   between images, so small feature maps (12x9, 8x6) still fill 128-pixel tiles.
+//   Pipeline: a stage = (tile, channel chunk).  While the MFMAs of stage s run out of LDS, the
+//   global loads of stage s+1 are already in flight into registers (issue-early / write-late);
+//   all per-vector index arithmetic is hoisted out of the stage loop.
+#include <stdlib.h>
 #include "common.cuh"
 
 namespace {
@@ -45,13 +49,16 @@ __device__ __forceinline__ void store8(void* base, size_t elem, const float* f) 
     }
 }
 
-template <typename T, int KS, int BN>
+// NVA: A (input halo) vectors per thread per stage; Q: source is BNBWD (second tensor on load)
+template <typename T, int KS, int BN, int NVA, bool Q>
 __global__ __launch_bounds__(256) void conv_core_kernel(const ConvK k) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KV = ET<T>::KV, CK = ET<T>::CK, TAPS = KS * KS, NT = BN / 16;
     constexpr int ROWB = TAPS * 64 + 16;
     constexpr int OSTR = BN + 4;
     constexpr int VPP = BN / 8;
+    constexpr int NVB = (BN * TAPS * 4 + 255) / 256;
+    constexpr int NSLOT = 128 * VPP / 256;
     const stl_conv& p = k.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.y * BN;
@@ -80,45 +87,169 @@ __global__ __launch_bounds__(256) void conv_core_kernel(const ConvK k) {
         }
     }
 
-    auto stage_b = [&](int k0) {
-        const int nvec = BN * TAPS * 4;
-        for (int v = tid; v < nvec; v += 256) {
+    // ---- loop-invariant per-thread descriptors
+    int a_rc[NVA];  // (halo row << 16) | halo col, -1 when this slot is unused
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+        const int v = tid + i * 256;
+        if (v < k.HP * 4) {
+            const int hp = v >> 2, hr = hp / k.HC;
+            a_rc[i] = (hr << 16) | (hp - hr * k.HC);
+        } else {
+            a_rc[i] = -1;
+        }
+    }
+    const int a_part = tid & 3;  // (tid + i*256) & 3
+    int b_g[NVB], b_l[NVB];      // weight element offset (without chunk) / LDS byte offset
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+        const int v = tid + i * 256;
+        b_g[i] = -1, b_l[i] = 0;
+        if (v < BN * TAPS * 4) {
             const int n = v / (TAPS * 4), r = v - n * (TAPS * 4), tap = r >> 2, part = r & 3;
-            const int co = n0 + n, ch = k0 + part * KV;
-            V16 val = zero16();
-            if (co < p.Co && ch < p.Ci)
-                val = ldg16((const char*)p.w + ((size_t)(co * TAPS + tap) * p.Ci + ch) * sizeof(T));
-            *reinterpret_cast<V16*>(sB + n * ROWB + tap * 64 + part * 16) = val;
+            b_l[i] = n * ROWB + tap * 64 + part * 16;
+            if (n0 + n < p.Co) b_g[i] = ((n0 + n) * TAPS + tap) * p.Ci + part * KV;
+        }
+    }
+    const int tilepx = p.TH * p.TW;
+    int aoff[2];  // lane's A row offsets for its two row tiles
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        int m = (wave * 2 + mi) * 16 + r16;
+        if (m >= tilepx) m = 0;
+        const int ty = m / p.TW, tx = m - ty * p.TW;
+        aoff[mi] = ((ty * k.seff) * k.HC + tx * k.seff) * PSA + g * 16;
+    }
+    const int boff = r16 * ROWB + g * 16;
+    const int cg = tid % VPP;
+    const int co = n0 + cg * 8;
+    int e_yx[NSLOT];  // epilogue pixel of slot s: (ty << 16) | tx, -1 unused
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        const int m = (tid + s * 256) / VPP;
+        if (m < tilepx) {
+            const int ty = m / p.TW;
+            e_yx[s] = (ty << 16) | (m - ty * p.TW);
+        } else {
+            e_yx[s] = -1;
+        }
+    }
+
+    // ---- staging registers + helpers
+    V16 ra[NVA], rq[Q ? NVA : 1], rb[NVB];
+    int a_go[NVA];  // element offset of this stage's tile pixel (+part), -1 = zero fill
+
+    auto tile_setup = [&](int t, int* go) {
+        const int tr = t / k.tiles_c, tc = t - tr * k.tiles_c;
+        const int vrs = tr * p.TH * k.seff, cb = tc * p.TW * k.seff - k.pad;
+        const int b0 = vrs / k.PI, y0 = vrs - b0 * k.PI - k.pad;
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            go[i] = -1;
+            if (a_rc[i] >= 0) {
+                int iy = y0 + (a_rc[i] >> 16), ix = cb + (a_rc[i] & 0xffff), b = b0;
+                if (iy >= 0 && ix >= 0) {
+                    while (iy >= k.PI) iy -= k.PI, ++b;
+                    bool ok;
+                    if (p.stuff) {
+                        ok = (b < p.B) && !((iy | ix) & 1) && ((iy >> 1) < p.Hi) && ((ix >> 1) < p.Wi);
+                        iy >>= 1, ix >>= 1;
+                    } else {
+                        ok = (b < p.B) && (iy < p.Hi) && (ix < p.Wi);
+                    }
+                    if (ok) go[i] = ((b * p.Hi + iy) * p.Wi + ix) * p.Ci + a_part * KV;
+                }
+            }
         }
     };
-    if (k.wres) stage_b(0);
+    auto issue = [&](const int* go, int k0) {
+        const bool chok = (k0 + a_part * KV) < p.Ci;
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            ra[i] = zero16();
+            if (Q) rq[i] = zero16();
+            if (go[i] >= 0 && chok) {
+                ra[i] = ldg16((const char*)p.src.x + (size_t)(go[i] + k0) * sizeof(T));
+                if (Q) rq[i] = ldg16((const char*)p.src.y + (size_t)(go[i] + k0) * sizeof(T));
+            }
+        }
+        if (!k.wres) {
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                rb[i] = zero16();
+                if (b_g[i] >= 0 && (k0 + ((tid + i * 256) & 3) * KV) < p.Ci)
+                    rb[i] = ldg16((const char*)p.w + (size_t)(b_g[i] + k0) * sizeof(T));
+            }
+        }
+    };
+    auto write_lds = [&](const int* go, int k0) {
+        const int ch = k0 + a_part * KV;
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            if (a_rc[i] < 0) continue;
+            V16 val = ra[i];
+            if (p.src.mode != STL_SRC_PLAIN && go[i] >= 0 && ch < p.Ci) {
+                float f[KV];
+                unpack<T>(val, f);
+                if (!Q) {
+#pragma unroll
+                    for (int j = 0; j < KV; ++j) {
+                        float u = cs[ch + j] * f[j] + cs[k.cipad + ch + j];
+                        f[j] = p.src.relu ? fmaxf(u, 0.f) : u;
+                    }
+                } else {
+                    float q[KV];
+                    unpack<T>(rq[i], q);
+#pragma unroll
+                    for (int j = 0; j < KV; ++j)
+                        f[j] = cs[ch + j] * f[j] + cs[k.cipad + ch + j] * q[j] + cs[2 * k.cipad + ch + j];
+                }
+                val = pack<T>(f);
+            }
+            const int v = tid + i * 256;
+            *reinterpret_cast<V16*>(sA + (v >> 2) * PSA + (v & 3) * 16) = val;
+        }
+        if (!k.wres) {
+#pragma unroll
+            for (int i = 0; i < NVB; ++i)
+                if (tid + i * 256 < BN * TAPS * 4) *reinterpret_cast<V16*>(sB + b_l[i]) = rb[i];
+        }
+    };
 
-    // statistics accumulators (this thread always handles channel group tid % VPP)
+    if (k.wres) {  // whole K fits one chunk: filters stay resident in LDS for all tiles
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            if (tid + i * 256 < BN * TAPS * 4) {
+                V16 val = zero16();
+                if (b_g[i] >= 0 && (((tid + i * 256) & 3) * KV) < p.Ci) val = ldg16((const char*)p.w + (size_t)b_g[i] * sizeof(T));
+                *reinterpret_cast<V16*>(sB + b_l[i]) = val;
+            }
+        }
+    }
+
+    // statistics accumulators (this thread always handles channel group cg)
     float acc_s0[8], acc_s1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc_s0[j] = acc_s1[j] = 0.f;
 
     const int xcd = blockIdx.x & 7, lx = blockIdx.x >> 3, nx = gridDim.x >> 3;
     const int T8 = (k.npt + 7) >> 3;
-    const int tilepx = p.TH * p.TW;
     const int vpitch = p.Ho + 1;
 
-    for (int it = lx; it < T8; it += nx) {
-        const int t = xcd * T8 + it;
-        if (t >= k.npt) break;
+    int it = lx;
+    int t = xcd * T8 + it;
+    bool have = (it < T8) && (t < k.npt);
+    if (have) {
+        tile_setup(t, a_go);
+        issue(a_go, 0);
+    }
+    __syncthreads();  // constants + resident filters visible
+
+    while (have) {
         const int tr = t / k.tiles_c, tc = t - tr * k.tiles_c;
         const int vr0 = tr * p.TH, c0 = tc * p.TW;
-
-        // lane's A row offsets for its two row tiles
-        int aoff[2];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            int m = (wave * 2 + mi) * 16 + r16;
-            if (m >= tilepx) m = 0;
-            const int ty = m / p.TW, tx = m - ty * p.TW;
-            aoff[mi] = ((ty * k.seff) * k.HC + tx * k.seff) * PSA + g * 16;
-        }
-        const int boff = r16 * ROWB + g * 16;
+        const int itn = it + nx, tn = xcd * T8 + itn;
+        const bool have_next = (itn < T8) && (tn < k.npt);
 
         f32x4 acc[2][NT];
 #pragma unroll
@@ -127,56 +258,15 @@ __global__ __launch_bounds__(256) void conv_core_kernel(const ConvK k) {
             for (int nt = 0; nt < NT; ++nt) acc[mi][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         for (int ch0 = 0; ch0 < k.nchunks; ++ch0) {
-            const int k0 = ch0 * CK;
-            __syncthreads();  // previous users of sA/sB/sOut are done
-            // ---- stage the input halo tile for channels [k0, k0+CK), transformed on load
-            for (int v = tid; v < k.HP * 4; v += 256) {
-                const int hp = v >> 2, part = v & 3;
-                const int hr = hp / k.HC, hc = hp - hr * k.HC;
-                const int ch = k0 + part * KV;
-                const int vri = vr0 * k.seff - k.pad + hr;
-                int ix = c0 * k.seff - k.pad + hc;
-                bool ok = (vri >= 0) && (ix >= 0) && (ch < p.Ci);
-                int b = 0, iy = 0;
-                if (ok) {
-                    b = vri / k.PI;
-                    iy = vri - b * k.PI;
-                    if (p.stuff) {
-                        ok = (b < p.B) && !((iy | ix) & 1) && ((iy >> 1) < p.Hi) && ((ix >> 1) < p.Wi);
-                        iy >>= 1;
-                        ix >>= 1;
-                    } else {
-                        ok = (b < p.B) && (iy < p.Hi) && (ix < p.Wi);
-                    }
-                }
-                V16 val = zero16();
-                if (ok) {
-                    const size_t off = (((size_t)b * p.Hi + iy) * p.Wi + ix) * p.Ci + ch;
-                    val = ldg16((const char*)p.src.x + off * sizeof(T));
-                    if (p.src.mode != STL_SRC_PLAIN) {
-                        float f[KV];
-                        unpack<T>(val, f);
-                        if (p.src.mode == STL_SRC_BN) {
-#pragma unroll
-                            for (int j = 0; j < KV; ++j) {
-                                float u = cs[ch + j] * f[j] + cs[k.cipad + ch + j];
-                                f[j] = p.src.relu ? fmaxf(u, 0.f) : u;
-                            }
-                        } else {
-                            float q[KV];
-                            V16 qv = ldg16((const char*)p.src.y + off * sizeof(T));
-                            unpack<T>(qv, q);
-#pragma unroll
-                            for (int j = 0; j < KV; ++j)
-                                f[j] = cs[ch + j] * f[j] + cs[k.cipad + ch + j] * q[j] + cs[2 * k.cipad + ch + j];
-                        }
-                        val = pack<T>(f);
-                    }
-                }
-                *reinterpret_cast<V16*>(sA + hp * PSA + part * 16) = val;
-            }
-            if (!k.wres) stage_b(k0);
+            write_lds(a_go, ch0 * CK);
             __syncthreads();
+            // ---- next stage's global loads go out now and land during the MFMAs below
+            if (ch0 + 1 < k.nchunks) {
+                issue(a_go, (ch0 + 1) * CK);
+            } else if (have_next) {
+                tile_setup(tn, a_go);
+                issue(a_go, 0);
+            }
             // ---- MFMA over the taps of this chunk
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
@@ -191,30 +281,32 @@ __global__ __launch_bounds__(256) void conv_core_kernel(const ConvK k) {
                     for (int mi = 0; mi < 2; ++mi) mma16<T>(acc[mi][nt], a[mi], b);
                 }
             }
+            __syncthreads();  // everyone is done with sA/sB of this stage
         }
         // ---- epilogue: accumulators -> LDS [pixel][channel] -> fused elementwise -> global
-        __syncthreads();
+        // (when filters are resident the output staging must not overwrite them)
+        float* so = k.wres ? reinterpret_cast<float*>(smem + k.off_b + BN * ROWB) : sOut;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    sOut[((wave * 2 + mi) * 16 + 4 * g + r) * OSTR + nt * 16 + r16] = acc[mi][nt][r];
+                    so[((wave * 2 + mi) * 16 + 4 * g + r) * OSTR + nt * 16 + r16] = acc[mi][nt][r];
         __syncthreads();
-        const int cg = tid % VPP;
-        const int co = n0 + cg * 8;
         if (co < p.Co) {
-            for (int v = tid; v < 128 * VPP; v += 256) {
-                const int m = v / VPP;
-                if (m >= tilepx) break;
-                const int ty = m / p.TW, tx = m - ty * p.TW;
-                const int vr = vr0 + ty, c = c0 + tx;
-                const int b = vr / vpitch, oy = vr - b * vpitch;
+            const int eb0 = vr0 / vpitch, ey0 = vr0 - eb0 * vpitch;
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                if (e_yx[s] < 0) continue;
+                const int m = (tid + s * 256) / VPP;
+                int oy = ey0 + (e_yx[s] >> 16), b = eb0;
+                const int c = c0 + (e_yx[s] & 0xffff);
+                while (oy >= vpitch) oy -= vpitch, ++b;
                 if (b >= p.B || oy >= p.Ho || c >= p.Wo) continue;
                 float f[8];
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(sOut + m * OSTR + cg * 8);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(sOut + m * OSTR + cg * 8 + 4);
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(so + m * OSTR + cg * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(so + m * OSTR + cg * 8 + 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) f[j] = lo[j], f[4 + j] = hi[j];
                 const size_t off = (((size_t)b * p.Ho + oy) * p.Wo + c) * p.Co + co;
@@ -255,6 +347,8 @@ __global__ __launch_bounds__(256) void conv_core_kernel(const ConvK k) {
                 store8<T>(p.out, off, f);
             }
         }
+        __syncthreads();  // output staging consumed before the next tile's write_lds
+        it = itn, t = tn, have = have_next;
     }
     // ---- flush statistics: deterministic in-block tree, then one fp64 atomic per channel
     double* dst = p.out_stats ? p.out_stats : p.red;
@@ -274,17 +368,27 @@ __global__ __launch_bounds__(256) void conv_core_kernel(const ConvK k) {
     }
 }
 
-template <typename T, int KS, int BN>
+template <typename T, int KS, int BN, int NVA, bool Q>
 int launch(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_core_kernel<T, KS, BN>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_core_kernel<T, KS, BN, NVA, Q>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_core_kernel<T, KS, BN>), grid, dim3(256), lds, st, k);
+    hipLaunchKernelGGL((conv_core_kernel<T, KS, BN, NVA, Q>), grid, dim3(256), lds, st, k);
     STL_LAUNCH_CHECK("conv_core");
     return 0;
+}
+
+template <typename T, int KS, int BN>
+int launch_nq(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+    const int nva = ceil_div(k.HP * 4, 256);
+    const bool q = k.p.src.mode == STL_SRC_BNBWD;
+    if (nva <= 3) return q ? launch<T, KS, BN, 3, true>(k, grid, lds, st) : launch<T, KS, BN, 3, false>(k, grid, lds, st);
+    if (nva <= 6) return q ? launch<T, KS, BN, 6, true>(k, grid, lds, st) : launch<T, KS, BN, 6, false>(k, grid, lds, st);
+    if (nva <= 9) return q ? launch<T, KS, BN, 9, true>(k, grid, lds, st) : launch<T, KS, BN, 9, false>(k, grid, lds, st);
+    return stl_set_error("conv: halo of %d pixels needs %d staging vectors per thread (max 9); shrink the tile", k.HP, nva);
 }
 
 }  // namespace
@@ -301,6 +405,8 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     STL_CHECK(p.Co % 8 == 0 && p.Co > 0, "conv: Co=%d must be a multiple of 8", p.Co);
     STL_CHECK(p.TH >= 1 && p.TW >= 1 && p.TH * p.TW <= 128, "conv: tile %dx%d exceeds 128 pixels", p.TH, p.TW);
     STL_CHECK(p.B > 0 && p.Hi > 0 && p.Wi > 0 && p.Ho > 0 && p.Wo > 0, "conv: empty tensor");
+    STL_CHECK((int64_t)p.B * p.Hi * p.Wi * p.Ci < (1ll << 31) && (int64_t)p.B * p.Ho * p.Wo * p.Co < (1ll << 31),
+              "conv: tensors of 2^31 or more elements are not supported");
     const int pad = p.ks == 3 ? 1 : 0;
     if (p.stuff) {
         STL_CHECK((p.Ho + 1) / 2 == p.Hi && (p.Wo + 1) / 2 == p.Wi, "conv(stuff): %dx%d is not the stride-2 image of %dx%d", p.Hi, p.Wi, p.Ho, p.Wo);
@@ -339,7 +445,7 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     const int rowb = k.taps * 64 + 16;
     const int szA = (k.HP * PSA + 15) & ~15, szB = BN * rowb;
     const int szOut = 128 * (BN + 4) * 4, szRed = 256 * 16 * 4;
-    int szMain = szA + szB;
+    int szMain = szA + szB + (k.wres ? szOut : 0);  // resident filters: output staging gets its own region
     if (szOut > szMain) szMain = szOut;
     if (szRed > szMain) szMain = szRed;
     k.off_cs = 0;
@@ -349,15 +455,22 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     const size_t lds = (size_t)k.off_main + szMain;
     STL_CHECK(lds <= 160 * 1024, "conv: tile needs %zu B of LDS (>160 KiB); shrink TH/TW", lds);
     int gx = ceil_div(k.npt, 8) * 8;
-    const int cap = (p.out_stats || p.red) ? 512 : 1024;
+    int cap = 1280;
+    if (const char* e = getenv("STL_CONV_GRID_CAP")) cap = atoi(e) > 0 ? (atoi(e) + 7) / 8 * 8 : cap;  // tuning knob
+    if (getenv("STL_CONV_DEBUG")) {
+        int nb = -1;
+        fprintf(stderr, "[stl conv] npt=%d grid=(%d,%d) lds=%zu HP=%d nchunks=%d wres=%d\n", k.npt, gx < cap ? gx : cap,
+                ceil_div(p.Co, BN), lds, k.HP, k.nchunks, k.wres);
+        (void)nb;
+    }
     if (gx > cap) gx = cap;
     dim3 grid(gx, ceil_div(p.Co, BN));
     hipStream_t st = (hipStream_t)stream;
-#define DISPATCH(T)                                                      \
-    if (p.ks == 3) {                                                     \
-        return BN == 32 ? launch<T, 3, 32>(k, grid, lds, st) : launch<T, 3, 64>(k, grid, lds, st); \
-    } else {                                                             \
-        return BN == 32 ? launch<T, 1, 32>(k, grid, lds, st) : launch<T, 1, 64>(k, grid, lds, st); \
+#define DISPATCH(T)                                                                                   \
+    if (p.ks == 3) {                                                                                  \
+        return BN == 32 ? launch_nq<T, 3, 32>(k, grid, lds, st) : launch_nq<T, 3, 64>(k, grid, lds, st); \
+    } else {                                                                                          \
+        return BN == 32 ? launch_nq<T, 1, 32>(k, grid, lds, st) : launch_nq<T, 1, 64>(k, grid, lds, st); \
     }
     if (p.dtype == STL_BF16) {
         DISPATCH(__bf16)

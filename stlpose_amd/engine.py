@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -43,7 +44,7 @@ def choose_tile(B: int, Ho: int, Wo: int, stride: int, ks: int, esz: int, bn_col
         th = max(1, min(128 // tw, vrows))
         hr, hc = (th - 1) * stride + ks, (tw - 1) * stride + ks
         lds = hr * hc * 80 + bn_cols * (ks * ks * 64 + 16) + 8192
-        if lds > 150 * 1024:
+        if lds > 150 * 1024 or hr * hc > 576:   # 576 halo pixels = 9 staging vectors per thread
             continue
         cols = math.ceil(Wo / tw) * tw
         rows = math.ceil(vrows / th) * th
@@ -144,6 +145,7 @@ class Engine:
         self.convs: List[ConvInfo] = []
         self.bns: List[BNInfo] = []
         self._keep: List = []  # keep ctypes structs / tensors alive
+        self._sched: Dict[int, Tuple] = {}
         self.act_bytes = 0
         # static I/O
         self.img = torch.zeros(B, 3, H, W, dtype=torch.float32, device=self.dev)
@@ -153,6 +155,9 @@ class Engine:
         nstat = sum(int(math.prod(s)) for k, s in store.reg.params if _is_bn_weight(k, store.reg)) * 2 * capi.NSHARD
         self.stats = torch.zeros(max(nstat, 1), dtype=torch.float64, device=self.dev)
         self.rstats = torch.zeros(max(nstat, 1), dtype=torch.float64, device=self.dev) if training else None
+        self.nstreams = int(os.environ.get("STLPOSE_STREAMS", "4"))
+        self._stream = 0
+        self._side = None
         self._stats_used = 0
         self._wk_elems = 0
         self._wk_fix: List[Tuple] = []
@@ -164,8 +169,12 @@ class Engine:
 
     # ------------------------------------------------------------------ allocation helpers
     def _alloc(self, nbytes: int) -> torch.Tensor:
+        """Every planned buffer lives as long as the engine: kernels hold raw pointers, so a tensor
+        that merely lost its last Python reference must never go back to the caching allocator."""
         self.act_bytes += nbytes
-        return torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        t = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        self._keep.append(t)
+        return t
 
     def _act_tensor(self, B, H, W, C) -> torch.Tensor:
         return self._alloc(B * H * W * C * self.esz)
@@ -201,11 +210,15 @@ class Engine:
         return s
 
     # ------------------------------------------------------------------ builder protocol (arch.walk)
+    def set_stream(self, s: int):
+        self._stream = s % self.nstreams
+
     def stem_input(self) -> Act:
         B, H, W = self.B, self.H, self.W
         Ho, Wo = H // 2, W // 2
         t = self._act_tensor(B, Ho, Wo, 32)
-        self.fwd_ops.append(("stl_patch3x3", (self.dtype, self.img.data_ptr(), t.data_ptr(), B, H, W, 2, None, None)))
+        self.fwd_ops.append(("stl_patch3x3", (self.dtype, self.img.data_ptr(), t.data_ptr(), B, H, W, 2, None, None),
+                             0, [], [t.data_ptr()]))
         return Act("plain", t, B, Ho, Wo, 32, needs_grad=False)
 
     def conv_bn(self, ck, bk, x: Act, cout, ks, stride, relu, patch=False) -> Act:
@@ -237,9 +250,9 @@ class Engine:
         if self.training:
             p.out_stats = self.stats.data_ptr() + 8 * bn.stats_off
         self._wk_fix.append((p, "w", ci.fwd_off))
-        self.fwd_ops.append(("stl_conv_forward", (p,)))
+        self.fwd_ops.append(("stl_conv_forward", (p,), self._stream, [x.ptr], [y.ptr]))
         x.consumers += 1
-        self.tape.append(("conv", x, y, ci, (kks, kstride)))
+        self.tape.append(("conv", x, y, ci, (kks, kstride), self._stream))
         return y
 
     def fuse(self, terms, relu) -> Act:
@@ -258,8 +271,8 @@ class Engine:
             p.t[i].shift = s
             a.consumers += 1
         p.out = z.ptr
-        self.fwd_ops.append(("stl_fuse_forward", (p,)))
-        self.tape.append(("fuse", terms, z, relu))
+        self.fwd_ops.append(("stl_fuse_forward", (p,), self._stream, [a.ptr for a, _, _ in terms], [z.ptr]))
+        self.tape.append(("fuse", terms, z, relu, self._stream))
         return z
 
     def head(self, key, x: Act, joints) -> torch.Tensor:
@@ -268,7 +281,7 @@ class Engine:
         self.head_w = st.master.data_ptr() + 4 * st.param_off[key + ".weight"]
         self.head_b = st.master.data_ptr() + 4 * st.param_off[key + ".bias"]
         self.fwd_ops.append(("stl_head_forward", (self.dtype, x.ptr, self.head_w, self.head_b, self.out.data_ptr(),
-                                                  x.B, x.H, x.W, x.C, joints)))
+                                                  x.B, x.H, x.W, x.C, joints), 0, [x.ptr], [self.out.data_ptr()]))
         x.consumers += 1
         self.tape.append(("head", x, key, joints))
         return self.out
@@ -313,14 +326,14 @@ class Engine:
                 args = [self.dtype, x.ptr, self.head_w, self.dout.data_ptr(), dx.data_ptr(), None, nblk,
                         x.B, x.H, x.W, x.C, joints]
                 self._head_bwd_args = (args, part_off)
-                ops.append(("stl_head_backward", args))
+                ops.append(("stl_head_backward", args, 0, [self.dout.data_ptr(), x.ptr], [dx.data_ptr()]))
                 x.grads.append(dx)
                 self.slabs.append(dict(part_off=part_off, grad_off=st.param_off[key + ".weight"], nsplit=nblk,
                                        Co=joints, Ci=x.C, ks=1, Cip=x.C, patch=0, stride=nel))
                 self.slabs.append(dict(part_off=part_off + joints * x.C, grad_off=st.param_off[key + ".bias"],
                                        nsplit=nblk, Co=joints, Ci=1, ks=1, Cip=1, patch=0, stride=nel))
             elif kind == "fuse":
-                _, terms, z, relu = node
+                _, terms, z, relu, strm = node
                 assert 1 <= len(z.grads) <= 4, f"fuse output has {len(z.grads)} gradient contributions"
                 p = capi.FuseBwd()
                 p.dtype, p.B, p.H, p.W, p.C = self.dtype, z.B, z.H, z.W, z.C
@@ -337,7 +350,7 @@ class Engine:
                 du = z.grads[0] if trivial else self._new_grad(z)
                 p.du = du.data_ptr()
                 if not trivial:
-                    ops.append(("stl_fuse_backward", (p,)))
+                    ops.append(("stl_fuse_backward", (p,), strm, [gt.data_ptr() for gt in z.grads], [du.data_ptr()]))
                 for a, s, _ in terms:
                     if a.kind == "plain":
                         assert s == 0, "upsampled plain terms do not occur in this network"
@@ -353,9 +366,9 @@ class Engine:
                         u.dt = a.dt.data_ptr()
                         u.bn = self._src(a)
                         u.rstats = self.rstats.data_ptr() + 8 * a.bn.stats_off
-                        ops.append(("stl_upsample_backward", (u,)))
+                        ops.append(("stl_upsample_backward", (u,), strm, [du.data_ptr()], [a.dt.data_ptr()]))
             else:  # conv
-                _, x, y, ci, (kks, kstride) = node
+                _, x, y, ci, (kks, kstride), strm = node
                 assert y.consumers == 1 and y.dt is not None, f"{ci.key}: BN activation must have exactly one consumer"
                 g = self._gsrc(y)
                 # ---- weight gradient
@@ -374,7 +387,7 @@ class Engine:
                 self._slab_elems += wg.nsplit * nel
                 self.slabs.append(dict(part_off=part_off, grad_off=ci.master_off, nsplit=wg.nsplit, Co=ci.Co, Ci=ci.Ci,
                                        ks=ci.ks, Cip=ci.Cik, patch=int(ci.patch), stride=0, struct=wg))
-                ops.append(("stl_conv_wgrad", (wg,)))
+                ops.append(("stl_conv_wgrad", (wg,), strm, [y.dt.data_ptr(), x.ptr], [id(wg)]))
                 # ---- data gradient
                 if not x.needs_grad:
                     continue
@@ -386,10 +399,13 @@ class Engine:
                 d.TH, d.TW = choose_tile(x.B, x.H, x.W, 1, kks, self.esz)
                 d.src = g
                 d.w = self.wk.data_ptr() + ci.bwd_off * self.esz
+                dreads = [y.dt.data_ptr()]
                 if x.kind == "plain":
                     out = self._new_grad(x)
                     if x.grads:
-                        d.addend = x.grads.pop().data_ptr()
+                        ad = x.grads.pop()
+                        d.addend = ad.data_ptr()
+                        dreads.append(ad.data_ptr())
                     x.grads.append(out)
                 else:
                     assert x.dt is None
@@ -399,7 +415,7 @@ class Engine:
                     d.mask_bn = self._src(x)
                     d.red = self.rstats.data_ptr() + 8 * x.bn.stats_off
                 d.out = out.data_ptr()
-                ops.append(("stl_conv_forward", (d,)))
+                ops.append(("stl_conv_forward", (d,), strm, dreads, [out.data_ptr()]))
         # slab arena + reduce table
         self.slab_arena = torch.empty(max(self._slab_elems, 1), dtype=torch.float32, device=self.dev)
         base = self.slab_arena.data_ptr()
@@ -417,7 +433,7 @@ class Engine:
             blk += math.ceil(s["Co"] * s["Ci"] * s["ks"] * s["ks"] / 1024)
         self._slab_blocks, self._slab_n = blk, len(self.slabs)
         self._slab_tab = _to_device(tab, self.dev)
-        self.bwd_ops = [(n, tuple(a)) for n, a in ops]
+        self.bwd_ops = [(n, tuple(a), st_, r, w) for n, a, st_, r, w in ops]
 
     def _build_tables(self):
         tab = (capi.BNRec * len(self.bns))()
@@ -429,12 +445,60 @@ class Engine:
         assert len(self.bns) == self.store.nnbt
 
     # ------------------------------------------------------------------ execution
+    def _schedule(self, ops):
+        """Cross-stream RAW dependencies: op index -> indices it must wait for / whether it records."""
+        last, waits, need = {}, [], set()
+        for i, (_, _, st_, reads, writes) in enumerate(ops):
+            w = set()
+            for r in reads:
+                j = last.get(r)
+                if j is not None and ops[j][2] != st_:
+                    w.add(j)
+                    need.add(j)
+            waits.append(sorted(w))
+            for t in writes:
+                last[t] = i
+        return waits, need
+
     def _run(self, ops, stream: int):
+        """Replay a program.  With nstreams > 1 the independent branches of each exchange module run
+        on side HIP streams (fork/join with events, capturable as parallel hipGraph branches)."""
         lib = self.lib
-        for name, args in ops:
-            rc = getattr(lib, name)(*args, stream)
+        if self.nstreams <= 1:
+            for name, args, *_ in ops:
+                rc = getattr(lib, name)(*args, stream)
+                if rc != 0:
+                    raise RuntimeError(f"{name}: {lib.stl_last_error().decode()}")
+            return
+        key = id(ops)
+        sched = self._sched.get(key)
+        if sched is None:
+            sched = self._sched[key] = self._schedule(ops)
+        waits, need = sched
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.dev) for _ in range(self.nstreams - 1)]
+        streams = [main] + self._side
+        e0 = torch.cuda.Event()
+        e0.record(main)
+        for s_ in self._side:
+            s_.wait_event(e0)
+        events = {}
+        for i, (name, args, st_, _, _) in enumerate(ops):
+            s_ = streams[st_]
+            for j in waits[i]:
+                s_.wait_event(events[j])
+            rc = getattr(lib, name)(*args, s_.cuda_stream)
             if rc != 0:
                 raise RuntimeError(f"{name}: {lib.stl_last_error().decode()}")
+            if i in need:
+                ev = torch.cuda.Event()
+                ev.record(s_)
+                events[i] = ev
+        for s_ in self._side:
+            ev = torch.cuda.Event()
+            ev.record(s_)
+            main.wait_event(ev)
 
     def prep_weights(self, stream: int):
         st = self.store

@@ -1,0 +1,123 @@
+"""Fused train step for the HRNet hot path: weights->kernel layout, forward, masked-MSE loss,
+backward, (RCCL gradient all-reduce), optimiser -- enqueued as one kernel stream and captured in
+HIP graphs so that a step costs a handful of host calls.
+
+Mirrors the reference's hot loop ``src/02_train.py:203-218`` (fwd -> PersonMSELoss -> backward ->
+optimizer.step) and replaces its ``nn.DataParallel`` (``02_train.py:109``) with one process per GPU
+and a bucketed all-reduce of the flat gradient buffer.  BatchNorm statistics stay
+per replica, like DataParallel's.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+
+from . import capi
+from .dp import FlatAllReduce
+from .hrnet import PoseHighResolutionNet
+
+ADAM, SGD = "adam", "sgd"
+
+
+class TrainStep:
+    def __init__(self, model: PoseHighResolutionNet, batch: int, height: int, width: int, optimizer: str = ADAM,
+                 lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 momentum: float = 0.9, nesterov: bool = False, process_group=None, bucket_mb: float = 32.0,
+                 use_graph: bool = True, device=None):
+        self.model = model
+        dev = torch.device(device or "cuda")
+        if not model._packed(dev):
+            model.to(dev)
+            model._pack(dev)
+        model.train()
+        self.dev = dev
+        self.store = model._store
+        self.eng = model.engine(batch, height, width, True)
+        self.kind = optimizer
+        self.pg = process_group
+        self.dp = FlatAllReduce(self.store.grads, process_group, bucket_mb) if process_group is not None else None
+        self.world = self.dp.world if self.dp is not None else 1
+        n = self.store.nparam
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev) if optimizer == ADAM else None
+        gscale = 1.0 / self.world
+        self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, momentum, float(nesterov), gscale],
+                                  dtype=torch.float32, device=dev)
+        self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        J = self.eng.out.shape[1]
+        self.target = torch.zeros_like(self.eng.out)
+        self.tweight = torch.ones(batch, J, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self._nblk = 512
+        self._partial = torch.zeros(self._nblk, dtype=torch.float64, device=dev)
+        # HIP-graph capture of a plan that forks onto >2 streams crashes inside hipStreamEndCapture
+        # on ROCm 7.2 ("graphs"); such plans are replayed eagerly on their streams.
+        if self.eng.nstreams > 2:
+            use_graph = False
+        self.use_graph = use_graph
+        self._g_fb: Optional[torch.cuda.CUDAGraph] = None
+        self._g_opt: Optional[torch.cuda.CUDAGraph] = None
+
+    # ------------------------------------------------------------------ pieces
+    def set_lr(self, lr: float):
+        self.hyper[0] = lr
+
+    def load_batch(self, img: torch.Tensor, target: torch.Tensor, target_weight: torch.Tensor):
+        self.eng.img.copy_(img, non_blocking=True)
+        self.target.copy_(target, non_blocking=True)
+        self.tweight.copy_(target_weight.reshape(self.tweight.shape), non_blocking=True)
+
+    def _fwd_bwd(self):
+        st = torch.cuda.current_stream().cuda_stream
+        e = self.eng
+        e.forward(st)
+        B, J = e.out.shape[:2]
+        capi.call("stl_mse_loss", e.out.data_ptr(), self.target.data_ptr(), self.tweight.data_ptr(), e.dout.data_ptr(),
+                  self._partial.data_ptr(), self._nblk, self.loss.data_ptr(), B, J, e.out[0, 0].numel(), 1.0, st)
+        e.backward(st)
+
+    def _optim(self):
+        st = torch.cuda.current_stream().cuda_stream
+        s = self.store
+        if self.kind == ADAM:
+            capi.call("stl_adam_step", s.master.data_ptr(), s.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                      s.nparam, self.hyper.data_ptr(), self.step_count.data_ptr(), st)
+        else:
+            capi.call("stl_sgd_step", s.master.data_ptr(), s.grads.data_ptr(), self.m.data_ptr(), s.nparam,
+                      self.hyper.data_ptr(), self.step_count.data_ptr(), st)
+
+    def _allreduce(self):
+        if self.dp is not None and self.world > 1:
+            self.dp.all_reduce()
+
+    def _capture(self):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):   # warm-up outside capture (lazy kernel attributes, allocator)
+            self._fwd_bwd()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_fb):
+            self._fwd_bwd()
+        self._g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_opt):
+            self._optim()
+        # the warm-up pass updated BN running stats once; harmless for training, documented
+
+    # ------------------------------------------------------------------ one step
+    def step(self) -> torch.Tensor:
+        """One train step on the currently loaded batch; returns the (device) loss scalar."""
+        if self.use_graph:
+            if self._g_fb is None:
+                self._capture()
+            self._g_fb.replay()
+            self._allreduce()
+            self._g_opt.replay()
+        else:
+            self._fwd_bwd()
+            self._allreduce()
+            self._optim()
+        return self.loss

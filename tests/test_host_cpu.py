@@ -74,7 +74,7 @@ def test_planner_dry_run():
     m = PoseHighResolutionNet("w32", "bf16")
     m._pack(torch.device("cpu"))
     e = Engine(m.arch, m._store, 2, 256, 192, capi.BF16, True)
-    f, b = Counter(n for n, _ in e.fwd_ops), Counter(n for n, _ in e.bwd_ops)
+    f, b = Counter(o[0] for o in e.fwd_ops), Counter(o[0] for o in e.bwd_ops)
     assert f["stl_conv_forward"] + f["stl_head_forward"] == 293
     assert b["stl_conv_wgrad"] == 292 and b["stl_conv_forward"] == 291 and b["stl_upsample_backward"] == 28
     assert len(e.bns) == 292 and e.out.shape == (2, 17, 64, 48)

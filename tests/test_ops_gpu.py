@@ -348,3 +348,63 @@ def test_error_reporting():
     p.dtype, p.ks, p.stride = 0, 5, 1
     with pytest.raises(RuntimeError, match="ks must be 1 or 3"):
         capi.call("stl_conv_forward", C.byref(p), stream())
+
+
+def test_weight_prep_and_reduce_slabs_tables():
+    """Table-driven batched helpers: OIHW master -> kernel layouts, and split-K slab reduction."""
+    import ctypes
+    g = torch.Generator(device="cuda").manual_seed(9)
+    shapes = [(8, 16, 3, 0), (16, 8, 1, 0), (64, 3, 3, 1)]   # Co, Ci, ks, patch
+    master = torch.randn(sum(co * ci * k * k for co, ci, k, _ in shapes), device="cuda", generator=g)
+    tab = (capi.WPrep * len(shapes))()
+    so, wo, blk = 0, 0, 0
+    offs = []
+    for i, (co, ci, k, patch) in enumerate(shapes):
+        cip = 32 if patch else ci
+        kk = 1 if patch else k * k
+        e = tab[i]
+        e.src_off, e.fwd_off, e.Co, e.Ci, e.ks, e.Cip, e.patch, e.blk0 = so, wo, co, ci, k, cip, patch, blk
+        fwd = wo
+        wo += co * kk * cip
+        e.bwd_off = -1 if patch else wo
+        if not patch:
+            wo += co * kk * cip
+        offs.append((so, fwd, e.bwd_off))
+        so += co * ci * k * k
+        blk += math.ceil(co * ci * k * k / 1024)
+    wk = torch.zeros(wo, device="cuda")
+    tdev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).cuda()
+    capi.call("stl_weight_prep", capi.F32, master.data_ptr(), wk.data_ptr(), tdev.data_ptr(), len(shapes), blk, stream())
+    torch.cuda.synchronize()
+    for (co, ci, k, patch), (s0, f0, b0) in zip(shapes, offs):
+        w = master[s0:s0 + co * ci * k * k].view(co, ci, k, k)
+        if patch:
+            ref = torch.zeros(co, 32, device="cuda")
+            ref[:, :27] = w.permute(0, 2, 3, 1).reshape(co, 27)
+            assert torch.equal(wk[f0:f0 + co * 32].view(co, 32), ref)
+        else:
+            assert torch.equal(wk[f0:f0 + co * k * k * ci].view(co, k * k, ci), w.permute(0, 2, 3, 1).reshape(co, k * k, ci))
+            refb = w.permute(1, 2, 3, 0).reshape(ci, k * k, co).flip(1)
+            assert torch.equal(wk[b0:b0 + co * k * k * ci].view(ci, k * k, co), refb)
+    # slabs: sum over splits, back to OIHW
+    st = (capi.Slab * len(shapes))()
+    po, go, blk = 0, 0, 0
+    parts, exp = [], []
+    for i, (co, ci, k, patch) in enumerate(shapes):
+        ns = 3 + i
+        kk, cik = (1, 32) if patch else (k * k, ci)
+        p = torch.randn(ns, co, kk, cik, device="cuda", generator=g)
+        parts.append(p.reshape(-1))
+        s = p.sum(0)
+        exp.append((s[:, 0, :27].view(co, 3, 3, 3).permute(0, 3, 1, 2) if patch else s.view(co, k, k, ci).permute(0, 3, 1, 2)).reshape(-1))
+        e = st[i]
+        e.part_off, e.grad_off, e.nsplit, e.Co, e.Ci, e.ks, e.Cip, e.patch, e.blk0, e.pad = po, go, ns, co, ci, k, cik, patch, blk, 0
+        po += p.numel()
+        go += co * ci * k * k
+        blk += math.ceil(co * ci * k * k / 1024)
+    partials = torch.cat(parts)
+    grads = torch.full((go,), float("nan"), device="cuda")
+    sdev = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).cuda()
+    capi.call("stl_reduce_slabs", partials.data_ptr(), grads.data_ptr(), sdev.data_ptr(), len(shapes), blk, stream())
+    torch.cuda.synchronize()
+    assert torch.allclose(grads, torch.cat(exp), rtol=1e-5, atol=1e-5)

@@ -1,0 +1,53 @@
+"""Micro-benchmark of one conv launch (dominant HRNet shapes) with tuning knobs from the environment."""
+import ctypes as C, math, os, sys, subprocess
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from stlpose_amd import capi
+from stlpose_amd.engine import choose_tile
+
+def run(B, H, W, Ci, Co, ks, s, mode="bn", reps=30, tile=None):
+    td = torch.bfloat16
+    x = torch.randn(B, H, W, Ci, device="cuda").to(td)
+    w = (torch.randn(Co, ks * ks, Ci, device="cuda") / math.sqrt(Ci * ks * ks)).to(td)
+    pad = 1 if ks == 3 else 0
+    Ho, Wo = (H + 2 * pad - ks) // s + 1, (W + 2 * pad - ks) // s + 1
+    out = torch.empty(B, Ho, Wo, Co, device="cuda", dtype=td)
+    st = torch.zeros(capi.NSHARD * 2 * Co, dtype=torch.float64, device="cuda")
+    sx = torch.zeros(capi.NSHARD, 2, Ci, dtype=torch.float64, device="cuda")
+    xf = x.float().reshape(-1, Ci).double()
+    sx[0, 0], sx[0, 1] = xf.sum(0), (xf * xf).sum(0)
+    ga, be = torch.ones(Ci, device="cuda"), torch.zeros(Ci, device="cuda")
+    p = capi.Conv()
+    p.dtype, p.B, p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.Co = capi.BF16, B, H, W, Ci, Ho, Wo, Co
+    p.ks, p.stride = ks, s
+    p.TH, p.TW = tile or choose_tile(B, Ho, Wo, s, ks, 2)
+    p.src.x = x.data_ptr()
+    if mode == "bn":
+        p.src.mode, p.src.relu = capi.SRC_BN, 1
+        p.src.stats, p.src.gamma, p.src.beta = sx.data_ptr(), ga.data_ptr(), be.data_ptr()
+        p.src.inv_count, p.src.eps = 1.0 / (B * H * W), 1e-5
+    p.w, p.out, p.out_stats = w.data_ptr(), out.data_ptr(), st.data_ptr()
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        capi.call("stl_conv_forward", C.byref(p), stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        capi.call("stl_conv_forward", C.byref(p), stream)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    fl = 2.0 * B * Ho * Wo * Co * Ci * ks * ks
+    by = B * H * W * Ci * 2 + B * Ho * Wo * Co * 2
+    print(f"B{B} {H}x{W} {Ci}->{Co} k{ks}s{s} tile={p.TH}x{p.TW} cap={os.environ.get('STL_CONV_GRID_CAP','-')}: {us:8.1f} us  {fl/us/1e6:7.1f} TF/s  {by/us/1e3:7.1f} GB/s", flush=True)
+
+if __name__ == "__main__":
+    shapes = [(32, 96, 72, 32, 32, 3, 1), (32, 48, 36, 64, 64, 3, 1), (32, 24, 18, 128, 128, 3, 1), (32, 12, 9, 256, 256, 3, 1),
+              (32, 96, 72, 64, 256, 1, 1), (32, 96, 72, 256, 64, 1, 1)]
+    if len(sys.argv) > 1 and sys.argv[1] == "one":
+        for sh in shapes:
+            run(*sh)
+    else:
+        for cap in ("256", "512", "768", "1024", "1280", "2560"):
+            env = dict(os.environ, STL_CONV_GRID_CAP=cap)
+            subprocess.run([sys.executable, __file__, "one"], env=env)
