@@ -46,9 +46,8 @@ def time_dominant_kernel(ts, reps=40):
     from stlpose_amd import capi
     eng = ts.eng
     cand = None
-    for name, args, *_ in eng.fwd_ops:
+    for name, p, *_ in eng.fwd_ops:
         if name == "stl_conv_forward":
-            p = args[0]
             if p.ks == 3 and p.stride == 1 and p.Ci == p.Co and p.Ho == eng.H // 4 and p.src.mode == capi.SRC_BN:
                 cand = p
                 break

@@ -59,7 +59,8 @@ typedef struct stl_conv {
     int32_t B, Hi, Wi, Ci; /* source tensor dims (for stuff=1: the half-size tensor) */
     int32_t Ho, Wo, Co;    /* output dims                                          */
     int32_t ks, stride, stuff;
-    int32_t TH, TW;        /* output tile (rows x cols), TH*TW <= 128              */
+    int32_t TH, TW;        /* output pixel tile; 0,0 = let stl_conv_plan choose      */
+    int32_t shape;         /* block shape id chosen by stl_conv_plan (-1 = choose at launch) */
     stl_src src;
     const void* w;         /* [Co][ks*ks][Ci] dtype                               */
     void* out;             /* [B,Ho,Wo,Co] dtype                                  */
@@ -72,6 +73,10 @@ typedef struct stl_conv {
     double* red;           /* [NSHARD][2*Co] += (r1,r2) against mask_y or NULL     */
 } stl_conv;
 int stl_conv_forward(const stl_conv* p, void* stream);
+/* Fill p->shape / p->TH / p->TW once (host-side tile search) so that launches are cheap. */
+int stl_conv_plan(stl_conv* p);
+/* Debug: phase time stamps (100 MHz ticks) of block 0 of the last conv launched with STL_CONV_STAMPS=1. */
+int stl_debug_conv_stamps(long long* host12);
 
 /* Weight gradient of the same convolution (aten::convolution_backward, weight part).
  * partial[s][co][tap][ci] (fp32) for s < nsplit; summed later by stl_reduce_slabs.
@@ -209,6 +214,33 @@ int stl_sum_partials(const double* partial, int n, double scale, float* out, int
 /* Layout / dtype utilities. */
 int stl_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H, int W, void* stream);
 int stl_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H, int W, void* stream);
+
+/* ---- native program replay (csrc/program.hip) --------------------------------------------------
+ * The Python planner turns the network into a flat list of the calls above; stl_program_run()
+ * enqueues all of them in one C call, on up to 16 HIP streams, with cross-stream RAW dependencies
+ * expressed as events (wait[] = indices of earlier ops that record). */
+#define STL_OP_CONV 0
+#define STL_OP_WGRAD 1
+#define STL_OP_FUSE 2
+#define STL_OP_FUSE_BWD 3
+#define STL_OP_UP_BWD 4
+#define STL_OP_PATCH 5
+#define STL_OP_HEAD 6
+#define STL_OP_HEAD_BWD 7
+typedef struct stl_patch { int32_t dtype, B, H, W, stride, pad_; const float* img; void* out; const float* mean3; const float* std3; } stl_patch;
+typedef struct stl_head { int32_t dtype, B, H, W, Ci, J; const void* x; const float* w; const float* bias; float* out; } stl_head;
+typedef struct stl_head_bwd { int32_t dtype, B, H, W, Ci, J, nblk, pad_; const void* x; const float* w; const float* dout; void* dx; float* partial; } stl_head_bwd;
+typedef struct stl_op {
+    int32_t kind;    /* STL_OP_*                                        */
+    int32_t stream;  /* index into the streams array given to run()      */
+    const void* desc; /* the op's descriptor struct (kept alive by the caller) */
+    int32_t nwait;
+    int32_t wait[6];
+    int32_t record;  /* 1: record an event after this op (someone waits on it) */
+} stl_op;
+int stl_program_create(const stl_op* ops, int n, int nstreams, void** out_handle);
+int stl_program_run(void* program, void* const* streams /* hipStream_t[nstreams]; [0] = main */);
+int stl_program_destroy(void* program);
 
 /* Self-checks that need no reference: MFMA / LDS-transpose lane maps (used by tests). */
 int stl_selftest_mfma(float* out /* [4] max abs err: bf16 mfma, f32 mfma, tr-read, f64 atomic */, void* stream);

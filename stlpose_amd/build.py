@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstlpose_hip.so")
-SOURCES = ["capi.hip", "conv_core.hip", "wgrad.hip", "elementwise.hip"]
+SOURCES = ["capi.hip", "conv_core.hip", "wgrad.hip", "elementwise.hip", "program.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 

@@ -24,7 +24,7 @@ class Src(C.Structure):
 
 class Conv(C.Structure):
     _fields_ = [("dtype", i32), ("B", i32), ("Hi", i32), ("Wi", i32), ("Ci", i32), ("Ho", i32), ("Wo", i32),
-                ("Co", i32), ("ks", i32), ("stride", i32), ("stuff", i32), ("TH", i32), ("TW", i32),
+                ("Co", i32), ("ks", i32), ("stride", i32), ("stuff", i32), ("TH", i32), ("TW", i32), ("shape", i32),
                 ("src", Src), ("w", vp), ("out", vp), ("bias", vp), ("out_relu", i32), ("out_stats", vp),
                 ("addend", vp), ("mask_y", vp), ("mask_bn", Src), ("red", vp)]
 
@@ -68,9 +68,33 @@ class BNRec(C.Structure):
     _fields_ = [("stats_off", i64), ("param_off", i64), ("buf_off", i64), ("C", i32), ("inv_count", f32)]
 
 
+class Patch(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("H", i32), ("W", i32), ("stride", i32), ("pad_", i32), ("img", vp), ("out", vp),
+                ("mean3", vp), ("std3", vp)]
+
+
+class Head(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("H", i32), ("W", i32), ("Ci", i32), ("J", i32), ("x", vp), ("w", vp),
+                ("bias", vp), ("out", vp)]
+
+
+class HeadBwd(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("H", i32), ("W", i32), ("Ci", i32), ("J", i32), ("nblk", i32), ("pad_", i32),
+                ("x", vp), ("w", vp), ("dout", vp), ("dx", vp), ("partial", vp)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", i32), ("stream", i32), ("desc", vp), ("nwait", i32), ("wait", i32 * 6), ("record", i32)]
+
+
+OP_KIND = {"stl_conv_forward": 0, "stl_conv_wgrad": 1, "stl_fuse_forward": 2, "stl_fuse_backward": 3,
+           "stl_upsample_backward": 4, "stl_patch3x3": 5, "stl_head_forward": 6, "stl_head_backward": 7}
+
 # name -> argtypes (restype is always int unless noted); every symbol include/stlpose_hip.h declares
 SIGNATURES = {
     "stl_conv_forward": [C.POINTER(Conv), vp],
+    "stl_conv_plan": [C.POINTER(Conv)],
+    "stl_debug_conv_stamps": [vp],
     "stl_conv_wgrad": [C.POINTER(Wgrad), vp],
     "stl_fuse_forward": [C.POINTER(Fuse), vp],
     "stl_fuse_backward": [C.POINTER(FuseBwd), vp],
@@ -94,6 +118,9 @@ SIGNATURES = {
     "stl_sum_partials": [vp, i32, C.c_double, vp, i32, vp],
     "stl_nchw_to_nhwc": [i32, vp, vp, i32, i32, i32, i32, vp],
     "stl_nhwc_to_nchw": [i32, vp, vp, i32, i32, i32, i32, vp],
+    "stl_program_create": [C.POINTER(Op), i32, i32, C.POINTER(vp)],
+    "stl_program_run": [vp, C.POINTER(vp)],
+    "stl_program_destroy": [vp],
     "stl_selftest_mfma": [vp, vp],
     "stl_version": [],
 }

@@ -2,96 +2,113 @@
 // halo tile and filter slice, "normalise on load" prologue and a fused epilogue.
 // One kernel serves the forward conv and (with transposed/flipped filters) the data gradient.
 //
-//   GEMM view:  M = output pixels (tile of <=128, 8 MFMA row tiles), N = BN output channels,
+//   GEMM view:  M = output channels (MFMA rows), N = output pixels (MFMA columns),
 //               K = taps x input channels, walked as 64-byte channel chunks (32 bf16 / 16 f32).
-//   Block = 256 threads = 4 waves; wave w owns row tiles {2w, 2w+1} x all BN/16 column tiles.
+//   The operands are swapped on purpose (filters = A, pixels = B): every lane then owns 4
+//   CONSECUTIVE output channels of one pixel, so the epilogue stores 8/16-byte vectors straight
+//   from the accumulators -- no LDS transpose, no extra barriers -- and reduces the BatchNorm
+//   sums in registers.
+//   Block = WM x WN waves; wave (wm, wn) owns MT pixel tiles x NTW channel tiles of 16x16.
 //   Pixel tiles are taken from "virtual rows": the batch is stacked along y with one zero row
-//   between images, so small feature maps (12x9, 8x6) still fill 128-pixel tiles.
+//   between images, so small feature maps (12x9, 8x6) still fill the tile.
 //   Pipeline: a stage = (tile, channel chunk).  While the MFMAs of stage s run out of LDS, the
 //   global loads of stage s+1 are already in flight into registers (issue-early / write-late);
 //   all per-vector index arithmetic is hoisted out of the stage loop.
+//   LDS strides (96 B per pixel, taps*64+32 B per filter row) are conflict-free for ds_read_b128.
 #include <stdlib.h>
 #include "common.cuh"
 
 namespace {
 
-constexpr int PSA = 80;  // LDS bytes per halo pixel: 64 B of channels + 16 B pad (bank spread)
+constexpr int PSA = 96;
+
+// debug-only phase stamps (block 0, thread 0; enabled by STL_CONV_STAMPS=1): never read by the kernel
+__device__ long long g_stamps[32];
+#define STAMP(i)                                                          \
+    do {                                                                  \
+        if (k.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); \
+    } while (0)
 
 struct ConvK {
     stl_conv p;
-    int tiles_c, npt;  // pixel tiles: columns, total
-    int HR, HC, HP;    // halo rows, cols, pixels
-    int PI, pad, seff; // source virtual pitch, padding, effective stride of the core
+    int tiles_c, npt;
+    int HR, HC, HP;
+    int PI, pad, seff;
     int nchunks, wres;
-    int cipad, copad;
-    int off_cs, off_cm, off_main, off_b;  // LDS byte offsets
-    int taps;
+    int cipad;
+    int off_cs, off_cm, off_a, off_b, off_red;
+    int TH, TW;
+    int dbg;
 };
 
 template <typename T>
-__device__ __forceinline__ void load8(const void* base, size_t elem, float* f) {
+__device__ __forceinline__ void load4(const void* base, size_t elem, float* f) {
     if constexpr (sizeof(T) == 2) {
-        V16 v = ldg16((const char*)base + elem * 2);
-        unpack<__bf16>(v, f);
+        const uint2 v = *reinterpret_cast<const uint2*>((const char*)base + elem * 2);
+        f[0] = __uint_as_float(v.x << 16), f[1] = __uint_as_float(v.x & 0xFFFF0000u);
+        f[2] = __uint_as_float(v.y << 16), f[3] = __uint_as_float(v.y & 0xFFFF0000u);
     } else {
-        V16 a = ldg16((const char*)base + elem * 4), b = ldg16((const char*)base + elem * 4 + 16);
-        unpack<float>(a, f);
-        unpack<float>(b, f + 4);
+        const V16 v = ldg16((const char*)base + elem * 4);
+        unpack<float>(v, f);
     }
 }
 template <typename T>
-__device__ __forceinline__ void store8(void* base, size_t elem, const float* f) {
+__device__ __forceinline__ void store4(void* base, size_t elem, const float* f) {
     if constexpr (sizeof(T) == 2) {
-        stg16((char*)base + elem * 2, pack<__bf16>(f));
+        uint2 v;
+        v.x = f32_to_bf16(f[0]) | (f32_to_bf16(f[1]) << 16);
+        v.y = f32_to_bf16(f[2]) | (f32_to_bf16(f[3]) << 16);
+        *reinterpret_cast<uint2*>((char*)base + elem * 2) = v;
     } else {
         stg16((char*)base + elem * 4, pack<float>(f));
-        stg16((char*)base + elem * 4 + 16, pack<float>(f + 4));
     }
 }
 
-// NVA: A (input halo) vectors per thread per stage; Q: source is BNBWD (second tensor on load)
-template <typename T, int KS, int BN, int NVA, bool Q>
-__global__ __launch_bounds__(256) void conv_core_kernel(const ConvK k) {
+// WM x WN waves, MT pixel tiles and NTW channel tiles per wave; NVA staging vectors per thread for
+// the input halo; Q: source is BNBWD (second tensor on load).
+template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, int OCC>
+__global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const ConvK k) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KV = ET<T>::KV, CK = ET<T>::CK, TAPS = KS * KS, NT = BN / 16;
-    constexpr int ROWB = TAPS * 64 + 16;
-    constexpr int OSTR = BN + 4;
-    constexpr int VPP = BN / 8;
-    constexpr int NVB = (BN * TAPS * 4 + 255) / 256;
-    constexpr int NSLOT = 128 * VPP / 256;
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int KV = ET<T>::KV, CK = ET<T>::CK, TAPS = KS * KS;
+    constexpr int BCO = WN * NTW * 16;
+    constexpr int ROWB = TAPS * 64 + 32;
+    constexpr int NVB = (BCO * TAPS * 4 + NTHR - 1) / NTHR;
     const stl_conv& p = k.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.y * BN;
+    const int wm = wave % WM, wn = wave / WM;
+    const int n0 = blockIdx.y * BCO;
 
+    STAMP(0);
     float* cs = reinterpret_cast<float*>(smem + k.off_cs);  // [3][cipad] source transform
-    float* cm = reinterpret_cast<float*>(smem + k.off_cm);  // [4][BN]    mask BN: a, b, mean, rstd
-    char* sA = smem + k.off_main;
+    float* cm = reinterpret_cast<float*>(smem + k.off_cm);  // [4][BCO]   mask BN: a, b, mean, rstd
+    char* sA = smem + k.off_a;
     char* sB = smem + k.off_b;
-    float* sOut = reinterpret_cast<float*>(smem + k.off_main);
 
     // ---- per-channel constants
-    for (int c = tid; c < k.cipad; c += 256) {
+    for (int c = tid; c < k.cipad; c += NTHR) {
         float a = 0.f, b = 0.f, cc = 0.f;
         if (c < p.Ci) src_consts(p.src, c, p.Ci, a, b, cc);
         cs[c] = a, cs[k.cipad + c] = b, cs[2 * k.cipad + c] = cc;
     }
     if (p.mask_y) {
-        for (int c = tid; c < BN; c += 256) {
+        for (int c = tid; c < BCO; c += NTHR) {
             float a = 0.f, b = 0.f, mu = 0.f, rs = 0.f;
             if (n0 + c < p.Co) {
                 bn_mean_rstd(p.mask_bn, n0 + c, p.Co, mu, rs);
                 a = p.mask_bn.gamma[n0 + c] * rs;
                 b = p.mask_bn.beta[n0 + c] - mu * a;
             }
-            cm[c] = a, cm[BN + c] = b, cm[2 * BN + c] = mu, cm[3 * BN + c] = rs;
+            cm[c] = a, cm[BCO + c] = b, cm[2 * BCO + c] = mu, cm[3 * BCO + c] = rs;
         }
     }
 
+    STAMP(1);
     // ---- loop-invariant per-thread descriptors
     int a_rc[NVA];  // (halo row << 16) | halo col, -1 when this slot is unused
 #pragma unroll
     for (int i = 0; i < NVA; ++i) {
-        const int v = tid + i * 256;
+        const int v = tid + i * NTHR;
         if (v < k.HP * 4) {
             const int hp = v >> 2, hr = hp / k.HC;
             a_rc[i] = (hr << 16) | (hp - hr * k.HC);
@@ -99,49 +116,43 @@ __global__ __launch_bounds__(256) void conv_core_kernel(const ConvK k) {
             a_rc[i] = -1;
         }
     }
-    const int a_part = tid & 3;  // (tid + i*256) & 3
-    int b_g[NVB], b_l[NVB];      // weight element offset (without chunk) / LDS byte offset
+    const int a_part = tid & 3;
+    int b_g[NVB], b_l[NVB];
 #pragma unroll
     for (int i = 0; i < NVB; ++i) {
-        const int v = tid + i * 256;
+        const int v = tid + i * NTHR;
         b_g[i] = -1, b_l[i] = 0;
-        if (v < BN * TAPS * 4) {
+        if (v < BCO * TAPS * 4) {
             const int n = v / (TAPS * 4), r = v - n * (TAPS * 4), tap = r >> 2, part = r & 3;
             b_l[i] = n * ROWB + tap * 64 + part * 16;
             if (n0 + n < p.Co) b_g[i] = ((n0 + n) * TAPS + tap) * p.Ci + part * KV;
         }
     }
-    const int tilepx = p.TH * p.TW;
-    int aoff[2];  // lane's A row offsets for its two row tiles
+    const int tilepx = k.TH * k.TW;
+    int xoff[MT];   // LDS offset of this lane's pixel (MFMA column r16) in each of its pixel tiles
+    int e_yx[MT];   // (ty << 16) | tx of that pixel, -1 when outside the tile
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        int m = (wave * 2 + mi) * 16 + r16;
-        if (m >= tilepx) m = 0;
-        const int ty = m / p.TW, tx = m - ty * p.TW;
-        aoff[mi] = ((ty * k.seff) * k.HC + tx * k.seff) * PSA + g * 16;
-    }
-    const int boff = r16 * ROWB + g * 16;
-    const int cg = tid % VPP;
-    const int co = n0 + cg * 8;
-    int e_yx[NSLOT];  // epilogue pixel of slot s: (ty << 16) | tx, -1 unused
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
-        const int m = (tid + s * 256) / VPP;
+    for (int mi = 0; mi < MT; ++mi) {
+        int m = (wm * MT + mi) * 16 + r16;
+        e_yx[mi] = -1;
         if (m < tilepx) {
-            const int ty = m / p.TW;
-            e_yx[s] = (ty << 16) | (m - ty * p.TW);
+            const int ty = m / k.TW;
+            e_yx[mi] = (ty << 16) | (m - ty * k.TW);
         } else {
-            e_yx[s] = -1;
+            m = 0;
         }
+        const int ty = m / k.TW, tx = m - ty * k.TW;
+        xoff[mi] = ((ty * k.seff) * k.HC + tx * k.seff) * PSA + g * 16;
     }
+    const int woff = (wn * NTW * 16 + r16) * ROWB + g * 16;
 
-    // ---- staging registers + helpers
+    STAMP(2);
     V16 ra[NVA], rq[Q ? NVA : 1], rb[NVB];
-    int a_go[NVA];  // element offset of this stage's tile pixel (+part), -1 = zero fill
+    int a_go[NVA];
 
     auto tile_setup = [&](int t, int* go) {
         const int tr = t / k.tiles_c, tc = t - tr * k.tiles_c;
-        const int vrs = tr * p.TH * k.seff, cb = tc * p.TW * k.seff - k.pad;
+        const int vrs = tr * k.TH * k.seff, cb = tc * k.TW * k.seff - k.pad;
         const int b0 = vrs / k.PI, y0 = vrs - b0 * k.PI - k.pad;
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
@@ -162,23 +173,22 @@ __global__ __launch_bounds__(256) void conv_core_kernel(const ConvK k) {
             }
         }
     };
-    auto issue = [&](const int* go, int k0) {
-        const bool chok = (k0 + a_part * KV) < p.Ci;
+    // Loads are UNCONDITIONAL (invalid slots read element 0 and are zeroed at write time): a
+    // guarded load makes hipcc branch around it and wait vmcnt(0) per element, which serialises
+    // the whole staging burst into dependent round trips.
+    auto issue = [&](const int* go, int k0, bool en) {
+        const bool chok = en && (k0 + a_part * KV) < p.Ci;
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
-            ra[i] = zero16();
-            if (Q) rq[i] = zero16();
-            if (go[i] >= 0 && chok) {
-                ra[i] = ldg16((const char*)p.src.x + (size_t)(go[i] + k0) * sizeof(T));
-                if (Q) rq[i] = ldg16((const char*)p.src.y + (size_t)(go[i] + k0) * sizeof(T));
-            }
+            const int off = (go[i] >= 0 && chok) ? go[i] + k0 : 0;
+            ra[i] = ldg16((const char*)p.src.x + (size_t)off * sizeof(T));
+            if (Q) rq[i] = ldg16((const char*)p.src.y + (size_t)off * sizeof(T));
         }
         if (!k.wres) {
 #pragma unroll
             for (int i = 0; i < NVB; ++i) {
-                rb[i] = zero16();
-                if (b_g[i] >= 0 && (k0 + ((tid + i * 256) & 3) * KV) < p.Ci)
-                    rb[i] = ldg16((const char*)p.w + (size_t)(b_g[i] + k0) * sizeof(T));
+                const bool ok = en && b_g[i] >= 0 && (k0 + ((tid + i * NTHR) & 3) * KV) < p.Ci;
+                rb[i] = ldg16((const char*)p.w + (size_t)(ok ? b_g[i] + k0 : 0) * sizeof(T));
             }
         }
     };
@@ -187,14 +197,16 @@ __global__ __launch_bounds__(256) void conv_core_kernel(const ConvK k) {
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
             if (a_rc[i] < 0) continue;
+            const bool ok = go[i] >= 0 && ch < p.Ci;
             V16 val = ra[i];
-            if (p.src.mode != STL_SRC_PLAIN && go[i] >= 0 && ch < p.Ci) {
+            if (p.src.mode != STL_SRC_PLAIN) {
                 float f[KV];
                 unpack<T>(val, f);
+                const int chc = ok ? ch : 0;
                 if (!Q) {
 #pragma unroll
                     for (int j = 0; j < KV; ++j) {
-                        float u = cs[ch + j] * f[j] + cs[k.cipad + ch + j];
+                        float u = cs[chc + j] * f[j] + cs[k.cipad + chc + j];
                         f[j] = p.src.relu ? fmaxf(u, 0.f) : u;
                     }
                 } else {
@@ -202,35 +214,44 @@ __global__ __launch_bounds__(256) void conv_core_kernel(const ConvK k) {
                     unpack<T>(rq[i], q);
 #pragma unroll
                     for (int j = 0; j < KV; ++j)
-                        f[j] = cs[ch + j] * f[j] + cs[k.cipad + ch + j] * q[j] + cs[2 * k.cipad + ch + j];
+                        f[j] = cs[chc + j] * f[j] + cs[k.cipad + chc + j] * q[j] + cs[2 * k.cipad + chc + j];
                 }
                 val = pack<T>(f);
             }
-            const int v = tid + i * 256;
+            const uint32_t keep = ok ? 0xFFFFFFFFu : 0u;  // zero padding applies AFTER the transform
+            val.w[0] &= keep, val.w[1] &= keep, val.w[2] &= keep, val.w[3] &= keep;
+            const int v = tid + i * NTHR;
             *reinterpret_cast<V16*>(sA + (v >> 2) * PSA + (v & 3) * 16) = val;
         }
         if (!k.wres) {
 #pragma unroll
-            for (int i = 0; i < NVB; ++i)
-                if (tid + i * 256 < BN * TAPS * 4) *reinterpret_cast<V16*>(sB + b_l[i]) = rb[i];
+            for (int i = 0; i < NVB; ++i) {
+                const bool ok = b_g[i] >= 0 && (k0 + ((tid + i * NTHR) & 3) * KV) < p.Ci;
+                const uint32_t keep = ok ? 0xFFFFFFFFu : 0u;
+                V16 val = rb[i];
+                val.w[0] &= keep, val.w[1] &= keep, val.w[2] &= keep, val.w[3] &= keep;
+                if (tid + i * NTHR < BCO * TAPS * 4) *reinterpret_cast<V16*>(sB + b_l[i]) = val;
+            }
         }
     };
 
     if (k.wres) {  // whole K fits one chunk: filters stay resident in LDS for all tiles
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
-            if (tid + i * 256 < BN * TAPS * 4) {
+            if (tid + i * NTHR < BCO * TAPS * 4) {
                 V16 val = zero16();
-                if (b_g[i] >= 0 && (((tid + i * 256) & 3) * KV) < p.Ci) val = ldg16((const char*)p.w + (size_t)b_g[i] * sizeof(T));
+                if (b_g[i] >= 0 && (((tid + i * NTHR) & 3) * KV) < p.Ci) val = ldg16((const char*)p.w + (size_t)b_g[i] * sizeof(T));
                 *reinterpret_cast<V16*>(sB + b_l[i]) = val;
             }
         }
     }
 
-    // statistics accumulators (this thread always handles channel group cg)
-    float acc_s0[8], acc_s1[8];
+    // statistics accumulators: this lane's 4 channels of each of its NTW channel tiles
+    float s0[NTW][4], s1[NTW][4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc_s0[j] = acc_s1[j] = 0.f;
+    for (int ni = 0; ni < NTW; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s0[ni][r] = s1[ni][r] = 0.f;
 
     const int xcd = blockIdx.x & 7, lx = blockIdx.x >> 3, nx = gridDim.x >> 3;
     const int T8 = (k.npt + 7) >> 3;
@@ -238,160 +259,316 @@ __global__ __launch_bounds__(256) void conv_core_kernel(const ConvK k) {
 
     int it = lx;
     int t = xcd * T8 + it;
+    int ch0 = 0;
     bool have = (it < T8) && (t < k.npt);
-    if (have) {
-        tile_setup(t, a_go);
-        issue(a_go, 0);
-    }
+    STAMP(3);
+    if (have) tile_setup(t, a_go);
+    issue(a_go, 0, have);
     __syncthreads();  // constants + resident filters visible
+    STAMP(4);
 
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // flat loop over stages (tile, chunk); exactly ONE issue() site inside the loop so that the
+    // staging registers need no PHI copies (which would force a vmcnt(0) before the MFMAs)
     while (have) {
         const int tr = t / k.tiles_c, tc = t - tr * k.tiles_c;
-        const int vr0 = tr * p.TH, c0 = tc * p.TW;
-        const int itn = it + nx, tn = xcd * T8 + itn;
-        const bool have_next = (itn < T8) && (tn < k.npt);
-
-        f32x4 acc[2][NT];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mi][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        for (int ch0 = 0; ch0 < k.nchunks; ++ch0) {
-            write_lds(a_go, ch0 * CK);
-            __syncthreads();
-            // ---- next stage's global loads go out now and land during the MFMAs below
-            if (ch0 + 1 < k.nchunks) {
-                issue(a_go, (ch0 + 1) * CK);
-            } else if (have_next) {
-                tile_setup(tn, a_go);
-                issue(a_go, 0);
-            }
-            // ---- MFMA over the taps of this chunk
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                const int toff = ((tap / KS) * k.HC + (tap % KS)) * PSA;
-                V16 a[2];
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const V16*>(sA + aoff[mi] + toff);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const V16 b = *reinterpret_cast<const V16*>(sB + boff + nt * 16 * ROWB + tap * 64);
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi) mma16<T>(acc[mi][nt], a[mi], b);
-                }
-            }
-            __syncthreads();  // everyone is done with sA/sB of this stage
-        }
-        // ---- epilogue: accumulators -> LDS [pixel][channel] -> fused elementwise -> global
-        // (when filters are resident the output staging must not overwrite them)
-        float* so = k.wres ? reinterpret_cast<float*>(smem + k.off_b + BN * ROWB) : sOut;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    so[((wave * 2 + mi) * 16 + 4 * g + r) * OSTR + nt * 16 + r16] = acc[mi][nt][r];
+        const int vr0 = tr * k.TH, c0 = tc * k.TW;
+        write_lds(a_go, ch0 * CK);
         __syncthreads();
-        if (co < p.Co) {
+        if (ch0 == 0) STAMP(5);
+        const bool last_chunk = (ch0 + 1 == k.nchunks);
+        int itn = it, tn = t, chn = ch0 + 1;
+        bool have_n = true;
+        if (last_chunk) {
+            itn = it + nx, tn = xcd * T8 + itn, chn = 0;
+            have_n = (itn < T8) && (tn < k.npt);
+            if (have_n) tile_setup(tn, a_go);
+        }
+        issue(a_go, chn * CK, have_n);  // next stage's loads land during the MFMAs below
+        if (ch0 == 0) STAMP(6);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int toff = ((tap / KS) * k.HC + (tap % KS)) * PSA;
+            V16 wf[NTW], xf[MT];
+#pragma unroll
+            for (int ni = 0; ni < NTW; ++ni) wf[ni] = *reinterpret_cast<const V16*>(sB + woff + ni * 16 * ROWB + tap * 64);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) xf[mi] = *reinterpret_cast<const V16*>(sA + xoff[mi] + toff);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NTW; ++ni) mma16<T>(acc[mi][ni], wf[ni], xf[mi]);
+        }
+        __syncthreads();  // everyone is done with sA/sB of this stage
+        if (ch0 == 0) STAMP(7);
+        if (last_chunk) {
+            STAMP(8);
+            // ---- epilogue straight from the accumulators: lane = pixel r16, 4 channels per tile
             const int eb0 = vr0 / vpitch, ey0 = vr0 - eb0 * vpitch;
 #pragma unroll
-            for (int s = 0; s < NSLOT; ++s) {
-                if (e_yx[s] < 0) continue;
-                const int m = (tid + s * 256) / VPP;
-                int oy = ey0 + (e_yx[s] >> 16), b = eb0;
-                const int c = c0 + (e_yx[s] & 0xffff);
-                while (oy >= vpitch) oy -= vpitch, ++b;
-                if (b >= p.B || oy >= p.Ho || c >= p.Wo) continue;
-                float f[8];
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(so + m * OSTR + cg * 8);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(so + m * OSTR + cg * 8 + 4);
+            for (int mi = 0; mi < MT; ++mi) {
+                bool pok = e_yx[mi] >= 0;
+                int oy = ey0 + (e_yx[mi] >> 16), b = eb0;
+                const int c = c0 + (e_yx[mi] & 0xffff);
+                if (pok) {
+                    while (oy >= vpitch) oy -= vpitch, ++b;
+                    pok = (b < p.B) && (oy < p.Ho) && (c < p.Wo);
+                }
+                const size_t pix = pok ? (((size_t)b * p.Ho + oy) * p.Wo + c) * p.Co : 0;
+                // issue every load of this pixel tile first (one round trip, not one per element)
+                float ad[NTW][4], my[NTW][4];
+                bool okv[NTW];
+                size_t eov[NTW];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) f[j] = lo[j], f[4 + j] = hi[j];
-                const size_t off = (((size_t)b * p.Ho + oy) * p.Wo + c) * p.Co + co;
-                if (p.bias) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) f[j] += p.bias[co + j];
+                for (int ni = 0; ni < NTW; ++ni) {
+                    const int co = n0 + (wn * NTW + ni) * 16 + 4 * g;
+                    okv[ni] = pok && co < p.Co;
+                    eov[ni] = okv[ni] ? pix + co : 0;  // invalid lanes read element 0, store nothing
                 }
                 if (p.addend) {
-                    float ad[8];
-                    load8<T>(p.addend, off, ad);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) f[j] += ad[j];
+                    for (int ni = 0; ni < NTW; ++ni) load4<T>(p.addend, eov[ni], ad[ni]);
                 }
-                float yh[8];
                 if (p.mask_y) {
-                    float my[8];
-                    load8<T>(p.mask_y, off, my);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int cl = cg * 8 + j;
-                        if (p.mask_bn.relu && !(cm[cl] * my[j] + cm[BN + cl] > 0.f)) f[j] = 0.f;
-                        yh[j] = (my[j] - cm[2 * BN + cl]) * cm[3 * BN + cl];
+                    for (int ni = 0; ni < NTW; ++ni) load4<T>(p.mask_y, eov[ni], my[ni]);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NTW; ++ni) {
+                    const int cl = (wn * NTW + ni) * 16 + 4 * g;  // channel within the block's BCO
+                    const int co = n0 + cl;
+                    const bool ok = okv[ni];
+                    float f[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) f[r] = acc[mi][ni][r];
+                    if (p.bias) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) f[r] += p.bias[ok ? co + r : 0];
                     }
+                    if (p.addend) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) f[r] += ad[ni][r];
+                    }
+                    float yh[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (p.mask_y) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (p.mask_bn.relu && !(cm[cl + r] * my[ni][r] + cm[BCO + cl + r] > 0.f)) f[r] = 0.f;
+                            yh[r] = (my[ni][r] - cm[2 * BCO + cl + r]) * cm[3 * BCO + cl + r];
+                        }
+                    }
+                    if (p.out_relu) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) f[r] = fmaxf(f[r], 0.f);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) f[r] = ok ? round_to<T>(f[r]) : 0.f;
+                    if (p.out_stats) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s0[ni][r] += f[r], s1[ni][r] += f[r] * f[r];
+                    } else if (p.red) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s0[ni][r] += f[r], s1[ni][r] += f[r] * yh[r];
+                    }
+                    if (ok) store4<T>(p.out, eov[ni], f);
+                    acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                if (p.out_relu) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], 0.f);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] = round_to<T>(f[j]);
-                if (p.out_stats) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc_s0[j] += f[j], acc_s1[j] += f[j] * f[j];
-                } else if (p.red) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc_s0[j] += f[j], acc_s1[j] += f[j] * yh[j];
-                }
-                store8<T>(p.out, off, f);
             }
         }
-        __syncthreads();  // output staging consumed before the next tile's write_lds
-        it = itn, t = tn, have = have_next;
+        if (last_chunk) STAMP(9);
+        it = itn, t = tn, ch0 = chn, have = have_n;
     }
-    // ---- flush statistics: deterministic in-block tree, then one fp64 atomic per channel
+    STAMP(10);
+    // ---- flush statistics: lanes of one 16-lane group hold the same channels -> xor-reduce them,
+    // then the WM waves of a channel column through LDS, then one fp64 atomic per channel
     double* dst = p.out_stats ? p.out_stats : p.red;
     if (dst) {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem + k.off_main);  // [256][16]
 #pragma unroll
-        for (int j = 0; j < 8; ++j) red[tid * 16 + j] = acc_s0[j], red[tid * 16 + 8 + j] = acc_s1[j];
+        for (int ni = 0; ni < NTW; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s0[ni][r] += __shfl_xor(s0[ni][r], o);
+                    s1[ni][r] += __shfl_xor(s1[ni][r], o);
+                }
+            }
+        float* red = reinterpret_cast<float*>(smem + k.off_red);  // [WM][2][BCO]
         __syncthreads();
-        if (tid < 2 * BN) {
-            const int which = tid / BN, cl = tid - which * BN, cgr = cl >> 3, j = cl & 7;
+        if (r16 == 0) {
+#pragma unroll
+            for (int ni = 0; ni < NTW; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cl = (wn * NTW + ni) * 16 + 4 * g + r;
+                    red[(wm * 2 + 0) * BCO + cl] = s0[ni][r];
+                    red[(wm * 2 + 1) * BCO + cl] = s1[ni][r];
+                }
+        }
+        __syncthreads();
+        for (int e = tid; e < 2 * BCO; e += NTHR) {
+            const int which = e / BCO, cl = e - which * BCO;
             float s = 0.f;
-            for (int q = cgr; q < 256; q += VPP) s += red[q * 16 + which * 8 + j];
+#pragma unroll
+            for (int w = 0; w < WM; ++w) s += red[(w * 2 + which) * BCO + cl];
             if (n0 + cl < p.Co)
                 atomicAdd(dst + (size_t)(blockIdx.x & (STL_NSHARD - 1)) * 2 * p.Co + which * p.Co + n0 + cl, (double)s);
         }
     }
+    STAMP(11);
 }
 
-template <typename T, int KS, int BN, int NVA, bool Q>
+template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, int OCC = 1>
 int launch(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_core_kernel<T, KS, BN, NVA, Q>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, OCC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_core_kernel<T, KS, BN, NVA, Q>), grid, dim3(256), lds, st, k);
+    hipLaunchKernelGGL((conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, OCC>), grid, dim3(64 * WM * WN), lds, st, k);
     STL_LAUNCH_CHECK("conv_core");
     return 0;
 }
 
-template <typename T, int KS, int BN>
-int launch_nq(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
-    const int nva = ceil_div(k.HP * 4, 256);
-    const bool q = k.p.src.mode == STL_SRC_BNBWD;
-    if (nva <= 3) return q ? launch<T, KS, BN, 3, true>(k, grid, lds, st) : launch<T, KS, BN, 3, false>(k, grid, lds, st);
-    if (nva <= 6) return q ? launch<T, KS, BN, 6, true>(k, grid, lds, st) : launch<T, KS, BN, 6, false>(k, grid, lds, st);
-    if (nva <= 9) return q ? launch<T, KS, BN, 9, true>(k, grid, lds, st) : launch<T, KS, BN, 9, false>(k, grid, lds, st);
-    return stl_set_error("conv: halo of %d pixels needs %d staging vectors per thread (max 9); shrink the tile", k.HP, nva);
+// block shapes: 0 = 128 px x 64 co (4 waves), 1 = 512 px x 32 co, 2 = 256 px x 64 co, 3 = 256 px x 128 co (8 waves),
+// 4 = 128 px x 32 co (4 waves, <=128 VGPRs, <=40 KB LDS: four blocks per CU hide each other's latency)
+struct Shape {
+    int px, co, thr;
+};
+constexpr int NSHAPES = 5;
+constexpr Shape SHAPES[NSHAPES] = {{128, 64, 256}, {512, 32, 512}, {256, 64, 512}, {256, 128, 512}, {128, 32, 256}};
+
+template <typename T, int KS, bool Q>
+int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+    switch (shape) {
+        case 0:
+            if (nva <= 3) return launch<T, KS, 4, 1, 2, 4, 3, Q>(k, grid, lds, st);
+            if (nva <= 9) return launch<T, KS, 4, 1, 2, 4, 9, Q>(k, grid, lds, st);
+            break;
+        case 1:
+            if (nva <= 6) return launch<T, KS, 8, 1, 4, 2, 6, Q>(k, grid, lds, st);
+            break;
+        case 2:
+            if (nva <= 3) return launch<T, KS, 4, 2, 4, 2, 3, Q>(k, grid, lds, st);
+            break;
+        case 3:
+            if (nva <= 3) return launch<T, KS, 4, 2, 4, 4, 3, Q>(k, grid, lds, st);
+            break;
+        case 4:
+            if (nva <= 3) return launch<T, KS, 4, 1, 2, 2, 3, Q, 4>(k, grid, lds, st);
+            if (nva <= 6) return launch<T, KS, 4, 1, 2, 2, 6, Q, 3>(k, grid, lds, st);
+            break;
+    }
+    return stl_set_error("conv: no kernel variant for block shape %d with %d staging vectors per thread", shape, nva);
+}
+
+struct Plan {
+    int shape, TH, TW;
+    size_t lds;
+    double cost;
+};
+
+// LDS bytes of a candidate (consts + input halo + filters + stats scratch)
+size_t lds_bytes(const stl_conv& p, int shape, int TH, int TW, int ck, ConvK* out) {
+    const int taps = p.ks * p.ks, seff = p.stride;
+    const int HR = (TH - 1) * seff + p.ks, HC = (TW - 1) * seff + p.ks;
+    const int nchunks = ceil_div(p.Ci, ck), cipad = nchunks * ck;
+    const int bco = SHAPES[shape].co;
+    int off = 3 * cipad * 4;
+    const int off_cm = off;
+    off += 4 * bco * 4;
+    off = (off + 15) & ~15;
+    const int off_a = off;
+    off += ((HR * HC * PSA) + 15) & ~15;
+    const int off_b = off;
+    off += bco * (taps * 64 + 32);
+    const int off_red = off_a;  // reused after the last stage
+    const int red = 8 * 2 * bco * 4;
+    if (off - off_a < red) off = off_a + red;
+    if (out) {
+        out->HR = HR, out->HC = HC, out->HP = HR * HC, out->nchunks = nchunks, out->cipad = cipad;
+        out->off_cs = 0, out->off_cm = off_cm, out->off_a = off_a, out->off_b = off_b, out->off_red = off_red;
+    }
+    return (size_t)off;
+}
+
+Plan choose_plan(const stl_conv& p, int ck) {
+    Plan best{-1, 0, 0, 0, 1e300};
+    const int vrows = p.B * (p.Ho + 1);
+    for (int shape = 0; shape < NSHAPES; ++shape) {
+        const Shape sh = SHAPES[shape];
+        if (shape != 0 && shape != 4 && p.stride == 2) continue;  // stride-2 halos only fit the small blocks
+        if (shape == 1 && p.Co > 32) continue;
+        if (shape == 2 && p.Co > 64 && p.Co % 64 != 0 && false) continue;
+        if (shape == 3 || shape == 4) continue;  // measured slower (register spills); reachable via STL_CONV_SHAPE only
+        const int nblk_co = ceil_div(p.Co, sh.co);
+        for (int tw = (p.Wo < 4 ? p.Wo : 4); tw <= p.Wo && tw <= sh.px; ++tw) {
+            int th = sh.px / tw;
+            if (th > vrows) th = vrows;
+            if (th < 1) continue;
+            const int hr = (th - 1) * p.stride + p.ks, hc = (tw - 1) * p.stride + p.ks;
+            const int nva = ceil_div(hr * hc * 4, sh.thr);
+            if ((shape == 0 && nva > 9) || (shape == 1 && nva > 6) || ((shape == 2 || shape == 3) && nva > 3) || (shape == 4 && nva > 6)) continue;
+            const size_t lds = lds_bytes(p, shape, th, tw, ck, nullptr);
+            if (shape == 4 && lds > 40 * 1024 && nva <= 3) continue;  // keep four blocks per CU
+            if (lds > 158 * 1024) continue;
+            const double tiles = (double)ceil_div(vrows, th) * ceil_div(p.Wo, tw);
+            // cost model (arbitrary units): MFMA work of all launched tiles (padding included), the
+            // bytes each tile stages (halo + filters), and a penalty when few blocks exist
+            const double mfma = tiles * sh.px * sh.co * nblk_co * (double)p.Ci * p.ks * p.ks / 2048.0;
+            const double bytes = tiles * nblk_co * ((double)hr * hc * p.Ci + (double)sh.co * p.ks * p.ks * p.Ci) * 2.0 / 12.0;
+            const double blocks = tiles * nblk_co;
+            double cost = (mfma > bytes ? mfma : bytes) + 0.3 * (mfma < bytes ? mfma : bytes);
+            const double waves = blocks * sh.thr / 64.0;
+            if (waves < 2048.0) cost *= 1.0 + 0.15 * (2048.0 / waves - 1.0 > 4.0 ? 4.0 : 2048.0 / waves - 1.0);
+            if (cost < best.cost) best = Plan{shape, th, tw, lds, cost};
+        }
+    }
+    return best;
 }
 
 }  // namespace
+
+extern "C" int stl_debug_conv_stamps(long long* host12) {
+    return hipMemcpyFromSymbol(host12, HIP_SYMBOL(g_stamps), 12 * sizeof(long long)) == hipSuccess ? 0 : stl_set_error("stamps: copy failed");
+}
+
+extern "C" int stl_conv_plan(stl_conv* pp) {
+    stl_conv& p = *pp;
+    STL_CHECK(p.dtype == STL_F32 || p.dtype == STL_BF16, "conv_plan: bad dtype");
+    STL_CHECK((p.ks == 1 || p.ks == 3) && (p.stride == 1 || p.stride == 2) && p.Ci > 0 && p.Co > 0, "conv_plan: bad geometry");
+    const int ck = p.dtype == STL_BF16 ? 32 : 16;
+    Plan plan = choose_plan(p, ck);
+    if (const char* e = getenv("STL_CONV_SHAPE")) {  // tuning knob: force a block shape where legal
+        const int f = atoi(e);
+        if (f >= 0 && f < NSHAPES && !(f != 0 && f != 4 && p.stride == 2)) {
+            Plan best{-1, 0, 0, 0, 1e300};
+            const int vrows = p.B * (p.Ho + 1);
+            const Shape sh = SHAPES[f];
+            for (int tw = (p.Wo < 4 ? p.Wo : 4); tw <= p.Wo && tw <= sh.px; ++tw) {
+                int th = sh.px / tw;
+                if (th > vrows) th = vrows;
+                const int hr = (th - 1) * p.stride + p.ks, hc = (tw - 1) * p.stride + p.ks;
+                const int nva = ceil_div(hr * hc * 4, sh.thr);
+                if ((f == 0 && nva > 9) || ((f == 1 || f == 4) && nva > 6) || ((f == 2 || f == 3) && nva > 3)) continue;
+                const size_t l = lds_bytes(p, f, th, tw, ck, nullptr);
+                if (l > 158 * 1024) continue;
+                const double waste = (double)ceil_div(vrows, th) * th * ceil_div(p.Wo, tw) * tw * (double)hr * hc / (th * tw);
+                if (waste < best.cost) best = Plan{f, th, tw, l, waste};
+            }
+            if (best.shape >= 0) plan = best;
+        }
+    }
+    STL_CHECK(plan.shape >= 0, "conv_plan: no tile fits LDS for %dx%d ks %d stride %d Ci %d", p.Ho, p.Wo, p.ks, p.stride, p.Ci);
+    p.shape = plan.shape, p.TH = plan.TH, p.TW = plan.TW;
+    return 0;
+}
 
 extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     const stl_conv& p = *pp;
@@ -403,7 +580,6 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     const int kv = p.dtype == STL_BF16 ? 8 : 4, ck = 4 * kv;
     STL_CHECK(p.Ci % kv == 0 && p.Ci > 0, "conv: Ci=%d must be a multiple of %d", p.Ci, kv);
     STL_CHECK(p.Co % 8 == 0 && p.Co > 0, "conv: Co=%d must be a multiple of 8", p.Co);
-    STL_CHECK(p.TH >= 1 && p.TW >= 1 && p.TH * p.TW <= 128, "conv: tile %dx%d exceeds 128 pixels", p.TH, p.TW);
     STL_CHECK(p.B > 0 && p.Hi > 0 && p.Wi > 0 && p.Ho > 0 && p.Wo > 0, "conv: empty tensor");
     STL_CHECK((int64_t)p.B * p.Hi * p.Wi * p.Ci < (1ll << 31) && (int64_t)p.B * p.Ho * p.Wo * p.Co < (1ll << 31),
               "conv: tensors of 2^31 or more elements are not supported");
@@ -424,54 +600,52 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     STL_CHECK(!p.red || p.mask_y, "conv: red needs mask_y");
     STL_CHECK(!p.mask_y || (p.mask_bn.gamma && p.mask_bn.beta && (p.mask_bn.stats || (p.mask_bn.rmean && p.mask_bn.rvar))), "conv: mask BN incomplete");
 
+    // block shape and pixel tile: planned once by stl_conv_plan (shape >= 0), else searched here
+    Plan plan;
+    if (p.shape >= 0 && p.shape < NSHAPES && p.TH > 0 && p.TW > 0) {
+        STL_CHECK(p.TH * p.TW <= SHAPES[p.shape].px, "conv: tile %dx%d exceeds block shape %d", p.TH, p.TW, p.shape);
+        plan = Plan{p.shape, p.TH, p.TW, 0, 0.0};
+    } else if (p.TH > 0 && p.TW > 0) {  // explicit 128-pixel tile (tests)
+        STL_CHECK(p.TH * p.TW <= 128, "conv: explicit tile %dx%d exceeds 128 pixels", p.TH, p.TW);
+        plan = Plan{0, p.TH, p.TW, 0, 0.0};
+    } else {
+        plan = choose_plan(p, ck);
+        STL_CHECK(plan.shape >= 0, "conv: no tile fits LDS for %dx%d ks %d stride %d Ci %d", p.Ho, p.Wo, p.ks, p.stride, p.Ci);
+    }
+    {
+        const Shape shp = SHAPES[plan.shape];
+        const int nv = ceil_div(((plan.TH - 1) * p.stride + p.ks) * ((plan.TW - 1) * p.stride + p.ks) * 4, shp.thr);
+        STL_CHECK(nv <= (plan.shape == 0 ? 9 : (plan.shape == 1 || plan.shape == 4) ? 6 : 3), "conv: tile %dx%d has too large a halo for block shape %d", plan.TH, plan.TW, plan.shape);
+    }
     ConvK k;
     k.p = p;
-    k.taps = p.ks * p.ks;
+    k.dbg = getenv("STL_CONV_STAMPS") ? 1 : 0;
     k.seff = p.stride;
     k.pad = pad;
     k.PI = p.stuff ? (p.Ho + 1) : p.stride * (p.Ho + 1);
-    k.HR = (p.TH - 1) * k.seff + p.ks;
-    k.HC = (p.TW - 1) * k.seff + p.ks;
-    k.HP = k.HR * k.HC;
-    const int vrows = p.B * (p.Ho + 1);
-    const int tiles_r = ceil_div(vrows, p.TH);
-    k.tiles_c = ceil_div(p.Wo, p.TW);
-    k.npt = tiles_r * k.tiles_c;
-    k.nchunks = ceil_div(p.Ci, ck);
+    k.TH = plan.TH, k.TW = plan.TW;
+    const size_t lds = lds_bytes(p, plan.shape, plan.TH, plan.TW, ck, &k);
+    STL_CHECK(lds <= 160 * 1024, "conv: tile needs %zu B of LDS (>160 KiB)", lds);
     k.wres = k.nchunks == 1;
-    k.cipad = k.nchunks * ck;
-    const int BN = (p.Co <= 32) ? 32 : 64;
-    k.copad = BN;
-    const int rowb = k.taps * 64 + 16;
-    const int szA = (k.HP * PSA + 15) & ~15, szB = BN * rowb;
-    const int szOut = 128 * (BN + 4) * 4, szRed = 256 * 16 * 4;
-    int szMain = szA + szB + (k.wres ? szOut : 0);  // resident filters: output staging gets its own region
-    if (szOut > szMain) szMain = szOut;
-    if (szRed > szMain) szMain = szRed;
-    k.off_cs = 0;
-    k.off_cm = 3 * k.cipad * 4;
-    k.off_main = (k.off_cm + 4 * BN * 4 + 15) & ~15;
-    k.off_b = k.off_main + szA;
-    const size_t lds = (size_t)k.off_main + szMain;
-    STL_CHECK(lds <= 160 * 1024, "conv: tile needs %zu B of LDS (>160 KiB); shrink TH/TW", lds);
+    const int vrows = p.B * (p.Ho + 1);
+    k.tiles_c = ceil_div(p.Wo, plan.TW);
+    k.npt = ceil_div(vrows, plan.TH) * k.tiles_c;
+    const Shape sh = SHAPES[plan.shape];
     int gx = ceil_div(k.npt, 8) * 8;
-    int cap = 1280;
-    if (const char* e = getenv("STL_CONV_GRID_CAP")) cap = atoi(e) > 0 ? (atoi(e) + 7) / 8 * 8 : cap;  // tuning knob
-    if (getenv("STL_CONV_DEBUG")) {
-        int nb = -1;
-        fprintf(stderr, "[stl conv] npt=%d grid=(%d,%d) lds=%zu HP=%d nchunks=%d wres=%d\n", k.npt, gx < cap ? gx : cap,
-                ceil_div(p.Co, BN), lds, k.HP, k.nchunks, k.wres);
-        (void)nb;
-    }
+    int cap = sh.thr == 512 ? 512 : (plan.shape == 4 ? 2048 : 1024);
+    if (const char* e = getenv("STL_CONV_GRID_CAP")) cap = atoi(e) > 0 ? (atoi(e) + 7) / 8 * 8 : cap;
     if (gx > cap) gx = cap;
-    dim3 grid(gx, ceil_div(p.Co, BN));
+    dim3 grid(gx, ceil_div(p.Co, sh.co));
+    const int nva = ceil_div(k.HP * 4, sh.thr);
+    if (getenv("STL_CONV_DEBUG"))
+        fprintf(stderr, "[stl conv] %dx%d Ci%d Co%d ks%d s%d: shape=%d tile=%dx%d npt=%d grid=(%d,%d) lds=%zu nva=%d nchunks=%d\n", p.Ho,
+                p.Wo, p.Ci, p.Co, p.ks, p.stride, plan.shape, plan.TH, plan.TW, k.npt, gx, grid.y, lds, nva, k.nchunks);
     hipStream_t st = (hipStream_t)stream;
-#define DISPATCH(T)                                                                                   \
-    if (p.ks == 3) {                                                                                  \
-        return BN == 32 ? launch_nq<T, 3, 32>(k, grid, lds, st) : launch_nq<T, 3, 64>(k, grid, lds, st); \
-    } else {                                                                                          \
-        return BN == 32 ? launch_nq<T, 1, 32>(k, grid, lds, st) : launch_nq<T, 1, 64>(k, grid, lds, st); \
-    }
+    const bool q = p.src.mode == STL_SRC_BNBWD;
+#define DISPATCH(T)                                                                                      \
+    if (p.ks == 3)                                                                                       \
+        return q ? dispatch<T, 3, true>(plan.shape, nva, k, grid, lds, st) : dispatch<T, 3, false>(plan.shape, nva, k, grid, lds, st); \
+    return q ? dispatch<T, 1, true>(plan.shape, nva, k, grid, lds, st) : dispatch<T, 1, false>(plan.shape, nva, k, grid, lds, st);
     if (p.dtype == STL_BF16) {
         DISPATCH(__bf16)
     } else {

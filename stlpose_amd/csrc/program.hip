@@ -1,0 +1,109 @@
+// Native replay of a planned kernel program: one C call enqueues every launch of the forward or
+// backward plan on its HIP streams, with the cross-stream dependencies expressed as events.
+// (The Python planner builds the op list once; per step the host does O(1) Python work.)
+#include <vector>
+#include "common.cuh"
+
+namespace {
+struct Program {
+    std::vector<stl_op> ops;
+    std::vector<hipEvent_t> ev;  // one per op with record != 0
+    std::vector<int> ev_of;      // op index -> event index or -1
+    hipEvent_t fork = nullptr;
+    std::vector<hipEvent_t> join;
+    int nstreams = 1;
+};
+}  // namespace
+
+extern "C" int stl_program_create(const stl_op* ops, int n, int nstreams, void** out) {
+    STL_CHECK(ops && out && n >= 0 && nstreams >= 1 && nstreams <= 16, "program_create: bad arguments");
+    Program* p = new Program();
+    p->ops.assign(ops, ops + n);
+    p->nstreams = nstreams;
+    p->ev_of.assign(n, -1);
+    for (int i = 0; i < n; ++i) {
+        const stl_op& o = ops[i];
+        if (o.stream < 0 || o.stream >= nstreams || o.nwait < 0 || o.nwait > 6 || !o.desc) {
+            delete p;
+            return stl_set_error("program_create: op %d malformed (stream %d, nwait %d)", i, o.stream, o.nwait);
+        }
+        for (int w = 0; w < o.nwait; ++w)
+            if (o.wait[w] < 0 || o.wait[w] >= i || !ops[o.wait[w]].record) {
+                delete p;
+                return stl_set_error("program_create: op %d waits on op %d which does not record an earlier event", i, o.wait[w]);
+            }
+        if (o.record) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+                delete p;
+                return stl_set_error("program_create: hipEventCreate failed");
+            }
+            p->ev_of[i] = (int)p->ev.size();
+            p->ev.push_back(e);
+        }
+    }
+    (void)hipEventCreateWithFlags(&p->fork, hipEventDisableTiming);
+    p->join.resize(nstreams);
+    for (int s = 0; s < nstreams; ++s) (void)hipEventCreateWithFlags(&p->join[s], hipEventDisableTiming);
+    *out = p;
+    return 0;
+}
+
+extern "C" int stl_program_destroy(void* h) {
+    Program* p = static_cast<Program*>(h);
+    if (!p) return 0;
+    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->join) (void)hipEventDestroy(e);
+    if (p->fork) (void)hipEventDestroy(p->fork);
+    delete p;
+    return 0;
+}
+
+extern "C" int stl_program_run(void* h, void* const* streams) {
+    Program* p = static_cast<Program*>(h);
+    STL_CHECK(p && streams, "program_run: null program");
+    hipStream_t main = (hipStream_t)streams[0];
+    if (p->nstreams > 1) {
+        STL_CHECK(hipEventRecord(p->fork, main) == hipSuccess, "program_run: fork record failed");
+        for (int s = 1; s < p->nstreams; ++s)
+            STL_CHECK(hipStreamWaitEvent((hipStream_t)streams[s], p->fork, 0) == hipSuccess, "program_run: fork wait failed");
+    }
+    const int n = (int)p->ops.size();
+    for (int i = 0; i < n; ++i) {
+        const stl_op& o = p->ops[i];
+        void* st = streams[o.stream];
+        for (int w = 0; w < o.nwait; ++w)
+            STL_CHECK(hipStreamWaitEvent((hipStream_t)st, p->ev[p->ev_of[o.wait[w]]], 0) == hipSuccess, "program_run: wait failed");
+        int rc;
+        switch (o.kind) {
+            case STL_OP_CONV: rc = stl_conv_forward(static_cast<const stl_conv*>(o.desc), st); break;
+            case STL_OP_WGRAD: rc = stl_conv_wgrad(static_cast<const stl_wgrad*>(o.desc), st); break;
+            case STL_OP_FUSE: rc = stl_fuse_forward(static_cast<const stl_fuse*>(o.desc), st); break;
+            case STL_OP_FUSE_BWD: rc = stl_fuse_backward(static_cast<const stl_fuse_bwd*>(o.desc), st); break;
+            case STL_OP_UP_BWD: rc = stl_upsample_backward(static_cast<const stl_upbwd*>(o.desc), st); break;
+            case STL_OP_PATCH: {
+                const stl_patch* a = static_cast<const stl_patch*>(o.desc);
+                rc = stl_patch3x3(a->dtype, a->img, a->out, a->B, a->H, a->W, a->stride, a->mean3, a->std3, st);
+                break;
+            }
+            case STL_OP_HEAD: {
+                const stl_head* a = static_cast<const stl_head*>(o.desc);
+                rc = stl_head_forward(a->dtype, a->x, a->w, a->bias, a->out, a->B, a->H, a->W, a->Ci, a->J, st);
+                break;
+            }
+            case STL_OP_HEAD_BWD: {
+                const stl_head_bwd* a = static_cast<const stl_head_bwd*>(o.desc);
+                rc = stl_head_backward(a->dtype, a->x, a->w, a->dout, a->dx, a->partial, a->nblk, a->B, a->H, a->W, a->Ci, a->J, st);
+                break;
+            }
+            default: return stl_set_error("program_run: op %d has unknown kind %d", i, o.kind);
+        }
+        if (rc != 0) return rc;
+        if (o.record) STL_CHECK(hipEventRecord(p->ev[p->ev_of[i]], (hipStream_t)st) == hipSuccess, "program_run: record failed");
+    }
+    for (int s = 1; s < p->nstreams; ++s) {
+        STL_CHECK(hipEventRecord(p->join[s], (hipStream_t)streams[s]) == hipSuccess, "program_run: join record failed");
+        STL_CHECK(hipStreamWaitEvent(main, p->join[s], 0) == hipSuccess, "program_run: join wait failed");
+    }
+    return 0;
+}

@@ -7,6 +7,8 @@
 // 2x2xTAPS 16x16 accumulators in registers across the block's tiles; the block reduces its
 // waves through LDS once and writes one fp32 slab [Co][taps][Ci] (deterministic split-K;
 // slabs are summed by stl_reduce_slabs).
+// Pipeline: the global loads of tile t+1 are issued (unconditionally, clamped addresses) before
+// the MFMAs of tile t and written to LDS after them; index arithmetic is hoisted out of the loop.
 #include "common.cuh"
 
 namespace {
@@ -45,13 +47,15 @@ __device__ __forceinline__ V16 frag_tr<float>(const char* base, const int* rowof
     return v;
 }
 
-template <typename T, int KS>
+// NVH: h (input halo) staging vectors per thread; GQ: g is BNBWD (second tensor on load)
+template <typename T, int KS, int NVH, bool GQ>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KV = ET<T>::KV, TAPS = KS * KS;
-    constexpr int KSTEP = 4 * KV;           // pixels per MFMA K step (32 bf16 / 16 f32)
+    constexpr int KSTEP = 4 * KV;               // pixels per MFMA K step (32 bf16 / 16 f32)
     constexpr int NR = sizeof(T) == 2 ? 2 : 4;  // row offsets a lane needs per fragment
-    constexpr int VPX = 32 / KV;            // 16-byte vectors per pixel (32 channels)
+    constexpr int VPX = 32 / KV;                // 16-byte vectors per pixel (32 channels)
+    constexpr int NVG = 128 * VPX / 256;        // g staging vectors per thread
     const stl_wgrad& p = k.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
     const int co0 = blockIdx.y * 32, ci0 = blockIdx.z * 32;
@@ -71,6 +75,142 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
         chc[t] = a, chc[32 + t] = b;
     }
 
+    const int tilepx = p.TH * p.TW;
+    const int vpitch = p.Ho + 1;
+    const int nks = (tilepx + KSTEP - 1) / KSTEP;
+
+    // ---- loop-invariant staging descriptors
+    int g_yx[NVG];  // (ty << 16) | tx of the tile pixel of slot i, -1 = beyond the tile (zero row)
+    const int g_part = tid % VPX;
+#pragma unroll
+    for (int i = 0; i < NVG; ++i) {
+        const int m = (tid + i * 256) / VPX;
+        g_yx[i] = -1;
+        if (m < tilepx) {
+            const int ty = m / p.TW;
+            g_yx[i] = (ty << 16) | (m - ty * p.TW);
+        }
+    }
+    int h_rc[NVH];
+#pragma unroll
+    for (int i = 0; i < NVH; ++i) {
+        const int v = tid + i * 256;
+        h_rc[i] = -1;
+        if (v < k.HP * VPX) {
+            const int hp = v / VPX, hr = hp / k.HC;
+            h_rc[i] = (hr << 16) | (hp - hr * k.HC);
+        }
+    }
+    const bool g_chok = (co0 + g_part * KV) < p.Co, h_chok = (ci0 + g_part * KV) < p.Ci;
+
+    // ---- MFMA-side offsets for this wave's K steps (tile geometry is the same for every tile)
+    // at most 2 K steps per wave (128 px / KSTEP / 4 waves: 1 for bf16, 2 for fp32)
+    constexpr int NKS = (128 / KSTEP + 3) / 4;
+    int rg[NKS][NR], rh[NKS][NR];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+        const int kb = (wave + 4 * s) * KSTEP;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            int m;
+            if constexpr (sizeof(T) == 2)
+                m = kb + 8 * g + 4 * i + ((lane & 15) >> 2);
+            else
+                m = kb + 4 * g + i;
+            if (m > 127) m = 127;
+            rg[s][i] = m * k.psg;  // rows >= tilepx are zero-filled in sG
+            if (m >= tilepx) m = 0;
+            const int ty = m / p.TW, tx = m - ty * p.TW;
+            rh[s][i] = ((ty * p.stride) * k.HC + tx * p.stride) * k.psh;
+        }
+    }
+
+    V16 rgv[NVG], rgq[GQ ? NVG : 1], rhv[NVH];
+    int g_go[NVG], h_go[NVH];
+
+    auto setup = [&](int t) {
+        const int tr = t / k.tiles_c, tc = t - tr * k.tiles_c;
+        const int vr0 = tr * p.TH, c0 = tc * p.TW;
+        const int gb0 = vr0 / vpitch, gy0 = vr0 - gb0 * vpitch;
+#pragma unroll
+        for (int i = 0; i < NVG; ++i) {
+            g_go[i] = -1;
+            if (g_yx[i] >= 0 && g_chok) {
+                int oy = gy0 + (g_yx[i] >> 16), b = gb0;
+                const int c = c0 + (g_yx[i] & 0xffff);
+                while (oy >= vpitch) oy -= vpitch, ++b;
+                if (b < p.B && oy < p.Ho && c < p.Wo) g_go[i] = ((b * p.Ho + oy) * p.Wo + c) * p.Co + co0 + g_part * KV;
+            }
+        }
+        const int vrs = vr0 * p.stride, cb = c0 * p.stride - k.pad;
+        const int hb0 = vrs / k.PI, hy0 = vrs - hb0 * k.PI - k.pad;
+#pragma unroll
+        for (int i = 0; i < NVH; ++i) {
+            h_go[i] = -1;
+            if (h_rc[i] >= 0 && h_chok) {
+                int iy = hy0 + (h_rc[i] >> 16), b = hb0;
+                const int ix = cb + (h_rc[i] & 0xffff);
+                if (iy >= 0 && ix >= 0 && ix < p.Wi) {
+                    while (iy >= k.PI) iy -= k.PI, ++b;
+                    if (b < p.B && iy < p.Hi) h_go[i] = ((b * p.Hi + iy) * p.Wi + ix) * p.Ci + ci0 + g_part * KV;
+                }
+            }
+        }
+    };
+    // unconditional loads (a guarded load would be serialised by the compiler); invalid slots read
+    // element 0 and are zeroed when written to LDS
+    auto issue = [&](bool en) {
+#pragma unroll
+        for (int i = 0; i < NVG; ++i) {
+            const size_t off = (en && g_go[i] >= 0) ? (size_t)g_go[i] : 0;
+            rgv[i] = ldg16((const char*)p.g.x + off * sizeof(T));
+            if (GQ) rgq[i] = ldg16((const char*)p.g.y + off * sizeof(T));
+        }
+#pragma unroll
+        for (int i = 0; i < NVH; ++i) {
+            const size_t off = (en && h_go[i] >= 0) ? (size_t)h_go[i] : 0;
+            rhv[i] = ldg16((const char*)p.h.x + off * sizeof(T));
+        }
+    };
+    auto write_lds = [&]() {
+        const int cl = g_part * KV;
+#pragma unroll
+        for (int i = 0; i < NVG; ++i) {
+            V16 val = rgv[i];
+            if (GQ) {
+                float f[KV], q[KV];
+                unpack<T>(val, f);
+                unpack<T>(rgq[i], q);
+#pragma unroll
+                for (int j = 0; j < KV; ++j) f[j] = cgc[cl + j] * f[j] + cgc[32 + cl + j] * q[j] + cgc[64 + cl + j];
+                val = pack<T>(f);
+            }
+            const uint32_t keep = g_go[i] >= 0 ? 0xFFFFFFFFu : 0u;
+            val.w[0] &= keep, val.w[1] &= keep, val.w[2] &= keep, val.w[3] &= keep;
+            const int v = tid + i * 256;
+            *reinterpret_cast<V16*>(sG + (v / VPX) * k.psg + g_part * 16) = val;
+        }
+#pragma unroll
+        for (int i = 0; i < NVH; ++i) {
+            if (h_rc[i] < 0) continue;
+            V16 val = rhv[i];
+            if (p.h.mode == STL_SRC_BN) {
+                float f[KV];
+                unpack<T>(val, f);
+#pragma unroll
+                for (int j = 0; j < KV; ++j) {
+                    float u = chc[cl + j] * f[j] + chc[32 + cl + j];
+                    f[j] = p.h.relu ? fmaxf(u, 0.f) : u;
+                }
+                val = pack<T>(f);
+            }
+            const uint32_t keep = h_go[i] >= 0 ? 0xFFFFFFFFu : 0u;
+            val.w[0] &= keep, val.w[1] &= keep, val.w[2] &= keep, val.w[3] &= keep;
+            const int v = tid + i * 256;
+            *reinterpret_cast<V16*>(sH + (v / VPX) * k.psh + g_part * 16) = val;
+        }
+    };
+
     f32x4 acc[2][2][TAPS];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -79,99 +219,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) acc[a][b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int tilepx = p.TH * p.TW;
-    const int vpitch = p.Ho + 1;
-    const int nks = (tilepx + KSTEP - 1) / KSTEP;
+    int t = blockIdx.x;
+    bool have = t < k.npt;
+    if (have) setup(t);
+    issue(have);
+    __syncthreads();  // constants visible
 
-    for (int t = blockIdx.x; t < k.npt; t += gridDim.x) {
-        const int tr = t / k.tiles_c, tc = t - tr * k.tiles_c;
-        const int vr0 = tr * p.TH, c0 = tc * p.TW;
+    while (have) {
+        write_lds();
         __syncthreads();
-        // ---- stage g tile: [tilepx][32 co], transformed (BN backward on load), zero for dummies
-        for (int v = tid; v < 128 * VPX; v += 256) {
-            const int m = v / VPX, part = v - m * VPX;
-            const int cl = part * KV;
-            V16 val = zero16();
-            if (m < tilepx) {
-                const int ty = m / p.TW, tx = m - ty * p.TW;
-                const int vr = vr0 + ty, c = c0 + tx;
-                const int b = vr / vpitch, oy = vr - b * vpitch;
-                if (b < p.B && oy < p.Ho && c < p.Wo && co0 + cl < p.Co) {
-                    const size_t off = (((size_t)b * p.Ho + oy) * p.Wo + c) * p.Co + co0 + cl;
-                    val = ldg16((const char*)p.g.x + off * sizeof(T));
-                    if (p.g.mode == STL_SRC_BNBWD) {
-                        float f[KV], q[KV];
-                        unpack<T>(val, f);
-                        V16 qv = ldg16((const char*)p.g.y + off * sizeof(T));
-                        unpack<T>(qv, q);
+        const int tn = t + gridDim.x;
+        const bool have_n = tn < k.npt;
+        if (have_n) setup(tn);
+        issue(have_n);  // next tile's loads fly during the MFMAs
 #pragma unroll
-                        for (int j = 0; j < KV; ++j) f[j] = cgc[cl + j] * f[j] + cgc[32 + cl + j] * q[j] + cgc[64 + cl + j];
-                        val = pack<T>(f);
+        for (int s = 0; s < NKS; ++s) {
+            if (wave + 4 * s < nks) {
+                V16 a[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) a[mt] = frag_tr<T>(sG, rg[s], mt * 16 * (int)sizeof(T), lane);
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap) {
+                    const int toff = ((tap / KS) * k.HC + (tap % KS)) * k.psh;
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const V16 b = frag_tr<T>(sH + toff, rh[s], nt * 16 * (int)sizeof(T), lane);
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) mma16<T>(acc[mt][nt][tap], a[mt], b);
                     }
                 }
             }
-            *reinterpret_cast<V16*>(sG + m * k.psg + part * 16) = val;
-        }
-        // ---- stage h halo tile: [HP][32 ci], transformed (BN + ReLU on load), zero padding
-        for (int v = tid; v < k.HP * VPX; v += 256) {
-            const int hp = v / VPX, part = v - hp * VPX;
-            const int hr = hp / k.HC, hc = hp - hr * k.HC;
-            const int cl = part * KV;
-            const int vri = vr0 * p.stride - k.pad + hr, ix = c0 * p.stride - k.pad + hc;
-            V16 val = zero16();
-            if (vri >= 0 && ix >= 0 && ix < p.Wi && ci0 + cl < p.Ci) {
-                const int b = vri / k.PI, iy = vri - b * k.PI;
-                if (b < p.B && iy < p.Hi) {
-                    const size_t off = (((size_t)b * p.Hi + iy) * p.Wi + ix) * p.Ci + ci0 + cl;
-                    val = ldg16((const char*)p.h.x + off * sizeof(T));
-                    if (p.h.mode == STL_SRC_BN) {
-                        float f[KV];
-                        unpack<T>(val, f);
-#pragma unroll
-                        for (int j = 0; j < KV; ++j) {
-                            float u = chc[cl + j] * f[j] + chc[32 + cl + j];
-                            f[j] = p.h.relu ? fmaxf(u, 0.f) : u;
-                        }
-                        val = pack<T>(f);
-                    }
-                }
-            }
-            *reinterpret_cast<V16*>(sH + hp * k.psh + part * 16) = val;
         }
         __syncthreads();
-        // ---- MFMA: this wave's K steps
-        for (int ks = wave; ks < nks; ks += 4) {
-            const int kb = ks * KSTEP;
-            int rg[NR], rh[NR];
-#pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                int m;
-                if constexpr (sizeof(T) == 2)
-                    m = kb + 8 * g + 4 * i + ((lane & 15) >> 2);  // row q of 4-pixel group i
-                else
-                    m = kb + 4 * g + i;
-                rg[i] = m * k.psg;  // rows >= tilepx are zero-filled in sG (m < 128 always)
-                if (m >= tilepx) m = 0;
-                const int ty = m / p.TW, tx = m - ty * p.TW;
-                rh[i] = ((ty * p.stride) * k.HC + tx * p.stride) * k.psh;
-            }
-            V16 a[2];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) a[mt] = frag_tr<T>(sG, rg, mt * 16 * (int)sizeof(T), lane);
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                const int toff = ((tap / KS) * k.HC + (tap % KS)) * k.psh;
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const V16 b = frag_tr<T>(sH + toff, rh, nt * 16 * (int)sizeof(T), lane);
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) mma16<T>(acc[mt][nt][tap], a[mt], b);
-                }
-            }
-        }
+        t = tn, have = have_n;
     }
     // ---- reduce the 4 waves through LDS, write this block's slab
-    __syncthreads();
     float* red = reinterpret_cast<float*>(smem + k.off_g);  // [4*TAPS][256]
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
@@ -199,17 +281,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
     }
 }
 
-template <typename T, int KS>
+template <typename T, int KS, int NVH, bool GQ>
 int launch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, KS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, KS, NVH, GQ>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((wgrad_kernel<T, KS>), grid, dim3(256), lds, st, k);
+    hipLaunchKernelGGL((wgrad_kernel<T, KS, NVH, GQ>), grid, dim3(256), lds, st, k);
     STL_LAUNCH_CHECK("conv_wgrad");
     return 0;
+}
+
+template <typename T, int KS>
+int dispatch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
+    const int vpx = 32 / ET<T>::KV;
+    const int nvh = ceil_div(k.HP * vpx, 256);
+    const bool gq = k.p.g.mode == STL_SRC_BNBWD;
+    if (nvh <= 3) return gq ? launch<T, KS, 3, true>(k, grid, lds, st) : launch<T, KS, 3, false>(k, grid, lds, st);
+    if (nvh <= 6) return gq ? launch<T, KS, 6, true>(k, grid, lds, st) : launch<T, KS, 6, false>(k, grid, lds, st);
+    if (nvh <= 9) return gq ? launch<T, KS, 9, true>(k, grid, lds, st) : launch<T, KS, 9, false>(k, grid, lds, st);
+    if (nvh <= 18) return gq ? launch<T, KS, 18, true>(k, grid, lds, st) : launch<T, KS, 18, false>(k, grid, lds, st);
+    return stl_set_error("wgrad: halo of %d pixels needs %d staging vectors per thread (max 18); shrink the tile", k.HP, nvh);
 }
 
 }  // namespace
@@ -222,6 +316,8 @@ extern "C" int stl_conv_wgrad(const stl_wgrad* pp, void* stream) {
     const int kv = p.dtype == STL_BF16 ? 8 : 4;
     STL_CHECK(p.Ci % kv == 0 && p.Co % kv == 0, "wgrad: Ci=%d / Co=%d must be multiples of %d", p.Ci, p.Co, kv);
     STL_CHECK(p.TH >= 1 && p.TW >= 1 && p.TH * p.TW <= 128, "wgrad: tile exceeds 128 pixels");
+    STL_CHECK((int64_t)p.B * p.Hi * p.Wi * p.Ci < (1ll << 31) && (int64_t)p.B * p.Ho * p.Wo * p.Co < (1ll << 31),
+              "wgrad: tensors of 2^31 or more elements are not supported");
     const int pad = p.ks == 3 ? 1 : 0;
     STL_CHECK((p.Hi + 2 * pad - p.ks) / p.stride + 1 == p.Ho && (p.Wi + 2 * pad - p.ks) / p.stride + 1 == p.Wo,
               "wgrad: output %dx%d inconsistent with input %dx%d", p.Ho, p.Wo, p.Hi, p.Wi);
@@ -255,6 +351,6 @@ extern "C" int stl_conv_wgrad(const stl_wgrad* pp, void* stream) {
     STL_CHECK(p.nsplit <= k.npt || p.nsplit == 1, "wgrad: nsplit %d > tiles %d", p.nsplit, k.npt);
     dim3 grid(p.nsplit, ceil_div(p.Co, 32), ceil_div(p.Ci, 32));
     hipStream_t st = (hipStream_t)stream;
-    if (p.dtype == STL_BF16) return p.ks == 3 ? launch<__bf16, 3>(k, grid, lds, st) : launch<__bf16, 1>(k, grid, lds, st);
-    return p.ks == 3 ? launch<float, 3>(k, grid, lds, st) : launch<float, 1>(k, grid, lds, st);
+    if (p.dtype == STL_BF16) return p.ks == 3 ? dispatch<__bf16, 3>(k, grid, lds, st) : dispatch<__bf16, 1>(k, grid, lds, st);
+    return p.ks == 3 ? dispatch<float, 3>(k, grid, lds, st) : dispatch<float, 1>(k, grid, lds, st);
 }

@@ -145,7 +145,7 @@ class Engine:
         self.convs: List[ConvInfo] = []
         self.bns: List[BNInfo] = []
         self._keep: List = []  # keep ctypes structs / tensors alive
-        self._sched: Dict[int, Tuple] = {}
+        self._progs: Dict[int, Tuple] = {}
         self.act_bytes = 0
         # static I/O
         self.img = torch.zeros(B, 3, H, W, dtype=torch.float32, device=self.dev)
@@ -156,6 +156,7 @@ class Engine:
         self.stats = torch.zeros(max(nstat, 1), dtype=torch.float64, device=self.dev)
         self.rstats = torch.zeros(max(nstat, 1), dtype=torch.float64, device=self.dev) if training else None
         self.nstreams = int(os.environ.get("STLPOSE_STREAMS", "4"))
+        self.wgrad_streams = os.environ.get("STLPOSE_WGRAD_STREAMS", "1") != "0"
         self._stream = 0
         self._side = None
         self._stats_used = 0
@@ -217,8 +218,10 @@ class Engine:
         B, H, W = self.B, self.H, self.W
         Ho, Wo = H // 2, W // 2
         t = self._act_tensor(B, Ho, Wo, 32)
-        self.fwd_ops.append(("stl_patch3x3", (self.dtype, self.img.data_ptr(), t.data_ptr(), B, H, W, 2, None, None),
-                             0, [], [t.data_ptr()]))
+        pd = capi.Patch()
+        pd.dtype, pd.B, pd.H, pd.W, pd.stride = self.dtype, B, H, W, 2
+        pd.img, pd.out = self.img.data_ptr(), t.data_ptr()
+        self.fwd_ops.append(("stl_patch3x3", pd, 0, [], [t.data_ptr()]))
         return Act("plain", t, B, Ho, Wo, 32, needs_grad=False)
 
     def conv_bn(self, ck, bk, x: Act, cout, ks, stride, relu, patch=False) -> Act:
@@ -244,13 +247,14 @@ class Engine:
         p.dtype = self.dtype
         p.B, p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.Co = x.B, x.H, x.W, x.C, Ho, Wo, cout
         p.ks, p.stride, p.stuff = kks, kstride, 0
-        p.TH, p.TW = choose_tile(x.B, Ho, Wo, kstride, kks, self.esz)
+        p.TH, p.TW, p.shape = 0, 0, -1
+        capi.call("stl_conv_plan", C.byref(p))  # block shape + pixel tile, searched once
         p.src = self._src(x)
         p.out = y.ptr
         if self.training:
             p.out_stats = self.stats.data_ptr() + 8 * bn.stats_off
         self._wk_fix.append((p, "w", ci.fwd_off))
-        self.fwd_ops.append(("stl_conv_forward", (p,), self._stream, [x.ptr], [y.ptr]))
+        self.fwd_ops.append(("stl_conv_forward", p, self._stream, [x.ptr], [y.ptr]))
         x.consumers += 1
         self.tape.append(("conv", x, y, ci, (kks, kstride), self._stream))
         return y
@@ -271,7 +275,7 @@ class Engine:
             p.t[i].shift = s
             a.consumers += 1
         p.out = z.ptr
-        self.fwd_ops.append(("stl_fuse_forward", (p,), self._stream, [a.ptr for a, _, _ in terms], [z.ptr]))
+        self.fwd_ops.append(("stl_fuse_forward", p, self._stream, [a.ptr for a, _, _ in terms], [z.ptr]))
         self.tape.append(("fuse", terms, z, relu, self._stream))
         return z
 
@@ -280,8 +284,10 @@ class Engine:
         self.out = torch.zeros(x.B, joints, x.H, x.W, dtype=torch.float32, device=self.dev)
         self.head_w = st.master.data_ptr() + 4 * st.param_off[key + ".weight"]
         self.head_b = st.master.data_ptr() + 4 * st.param_off[key + ".bias"]
-        self.fwd_ops.append(("stl_head_forward", (self.dtype, x.ptr, self.head_w, self.head_b, self.out.data_ptr(),
-                                                  x.B, x.H, x.W, x.C, joints), 0, [x.ptr], [self.out.data_ptr()]))
+        hd = capi.Head()
+        hd.dtype, hd.B, hd.H, hd.W, hd.Ci, hd.J = self.dtype, x.B, x.H, x.W, x.C, joints
+        hd.x, hd.w, hd.bias, hd.out = x.ptr, self.head_w, self.head_b, self.out.data_ptr()
+        self.fwd_ops.append(("stl_head_forward", hd, 0, [x.ptr], [self.out.data_ptr()]))
         x.consumers += 1
         self.tape.append(("head", x, key, joints))
         return self.out
@@ -323,10 +329,11 @@ class Engine:
                 nel = joints * x.C + joints
                 part_off = self._slab_elems
                 self._slab_elems += nblk * nel
-                args = [self.dtype, x.ptr, self.head_w, self.dout.data_ptr(), dx.data_ptr(), None, nblk,
-                        x.B, x.H, x.W, x.C, joints]
-                self._head_bwd_args = (args, part_off)
-                ops.append(("stl_head_backward", args, 0, [self.dout.data_ptr(), x.ptr], [dx.data_ptr()]))
+                hb = capi.HeadBwd()
+                hb.dtype, hb.B, hb.H, hb.W, hb.Ci, hb.J, hb.nblk = self.dtype, x.B, x.H, x.W, x.C, joints, nblk
+                hb.x, hb.w, hb.dout, hb.dx = x.ptr, self.head_w, self.dout.data_ptr(), dx.data_ptr()
+                self._head_bwd_args = (hb, part_off)
+                ops.append(("stl_head_backward", hb, 0, [self.dout.data_ptr(), x.ptr], [dx.data_ptr()]))
                 x.grads.append(dx)
                 self.slabs.append(dict(part_off=part_off, grad_off=st.param_off[key + ".weight"], nsplit=nblk,
                                        Co=joints, Ci=x.C, ks=1, Cip=x.C, patch=0, stride=nel))
@@ -350,7 +357,7 @@ class Engine:
                 du = z.grads[0] if trivial else self._new_grad(z)
                 p.du = du.data_ptr()
                 if not trivial:
-                    ops.append(("stl_fuse_backward", (p,), strm, [gt.data_ptr() for gt in z.grads], [du.data_ptr()]))
+                    ops.append(("stl_fuse_backward", p, strm, [gt.data_ptr() for gt in z.grads], [du.data_ptr()]))
                 for a, s, _ in terms:
                     if a.kind == "plain":
                         assert s == 0, "upsampled plain terms do not occur in this network"
@@ -366,7 +373,7 @@ class Engine:
                         u.dt = a.dt.data_ptr()
                         u.bn = self._src(a)
                         u.rstats = self.rstats.data_ptr() + 8 * a.bn.stats_off
-                        ops.append(("stl_upsample_backward", (u,), strm, [du.data_ptr()], [a.dt.data_ptr()]))
+                        ops.append(("stl_upsample_backward", u, strm, [du.data_ptr()], [a.dt.data_ptr()]))
             else:  # conv
                 _, x, y, ci, (kks, kstride), strm = node
                 assert y.consumers == 1 and y.dt is not None, f"{ci.key}: BN activation must have exactly one consumer"
@@ -387,7 +394,10 @@ class Engine:
                 self._slab_elems += wg.nsplit * nel
                 self.slabs.append(dict(part_off=part_off, grad_off=ci.master_off, nsplit=wg.nsplit, Co=ci.Co, Ci=ci.Ci,
                                        ks=ci.ks, Cip=ci.Cik, patch=int(ci.patch), stride=0, struct=wg))
-                ops.append(("stl_conv_wgrad", (wg,), strm, [y.dt.data_ptr(), x.ptr], [id(wg)]))
+                # weight gradients are off the critical path (only the data-gradient chain is): give
+                # them their own streams so they overlap with the chain
+                wstrm = (strm + self.nstreams) if self.wgrad_streams else strm
+                ops.append(("stl_conv_wgrad", wg, wstrm, [y.dt.data_ptr(), x.ptr], [id(wg)]))
                 # ---- data gradient
                 if not x.needs_grad:
                     continue
@@ -396,7 +406,8 @@ class Engine:
                 d.B, d.Hi, d.Wi, d.Ci = y.B, y.H, y.W, y.C
                 d.Ho, d.Wo, d.Co = x.H, x.W, x.C
                 d.ks, d.stride, d.stuff = kks, 1, int(kstride == 2)
-                d.TH, d.TW = choose_tile(x.B, x.H, x.W, 1, kks, self.esz)
+                d.TH, d.TW, d.shape = 0, 0, -1
+                capi.call("stl_conv_plan", C.byref(d))
                 d.src = g
                 d.w = self.wk.data_ptr() + ci.bwd_off * self.esz
                 dreads = [y.dt.data_ptr()]
@@ -415,12 +426,12 @@ class Engine:
                     d.mask_bn = self._src(x)
                     d.red = self.rstats.data_ptr() + 8 * x.bn.stats_off
                 d.out = out.data_ptr()
-                ops.append(("stl_conv_forward", (d,), strm, dreads, [out.data_ptr()]))
+                ops.append(("stl_conv_forward", d, strm, dreads, [out.data_ptr()]))
         # slab arena + reduce table
         self.slab_arena = torch.empty(max(self._slab_elems, 1), dtype=torch.float32, device=self.dev)
         base = self.slab_arena.data_ptr()
-        args, off = self._head_bwd_args
-        args[5] = base + 4 * off
+        hb, off = self._head_bwd_args
+        hb.partial = base + 4 * off
         for s in self.slabs:
             if "struct" in s:
                 s["struct"].partial = base + 4 * s["part_off"]
@@ -433,7 +444,7 @@ class Engine:
             blk += math.ceil(s["Co"] * s["Ci"] * s["ks"] * s["ks"] / 1024)
         self._slab_blocks, self._slab_n = blk, len(self.slabs)
         self._slab_tab = _to_device(tab, self.dev)
-        self.bwd_ops = [(n, tuple(a), st_, r, w) for n, a, st_, r, w in ops]
+        self.bwd_ops = ops
 
     def _build_tables(self):
         tab = (capi.BNRec * len(self.bns))()
@@ -460,45 +471,44 @@ class Engine:
                 last[t] = i
         return waits, need
 
-    def _run(self, ops, stream: int):
-        """Replay a program.  With nstreams > 1 the independent branches of each exchange module run
-        on side HIP streams (fork/join with events, capturable as parallel hipGraph branches)."""
-        lib = self.lib
-        if self.nstreams <= 1:
-            for name, args, *_ in ops:
-                rc = getattr(lib, name)(*args, stream)
-                if rc != 0:
-                    raise RuntimeError(f"{name}: {lib.stl_last_error().decode()}")
-            return
+    def _program(self, ops):
+        """Compile an op list into a native program (csrc/program.hip), once."""
         key = id(ops)
-        sched = self._sched.get(key)
-        if sched is None:
-            sched = self._sched[key] = self._schedule(ops)
-        waits, need = sched
-        main = torch.cuda.current_stream()
+        prog = self._progs.get(key)
+        if prog is None:
+            waits, need = self._schedule(ops)
+            arr = (capi.Op * max(len(ops), 1))()
+            for i, (name, desc, st_, _, _) in enumerate(ops):
+                o = arr[i]
+                o.kind, o.stream, o.desc = capi.OP_KIND[name], st_, C.addressof(desc)
+                assert len(waits[i]) <= 6, "op waits on more than 6 producers"
+                o.nwait = len(waits[i])
+                for j, wv in enumerate(waits[i]):
+                    o.wait[j] = wv
+                o.record = int(i in need)
+            h = C.c_void_p()
+            capi.call("stl_program_create", arr, len(ops), self.total_streams, C.byref(h))
+            prog = self._progs[key] = (h, arr)
+        return prog[0]
+
+    @property
+    def total_streams(self) -> int:
+        return self.nstreams * (2 if self.wgrad_streams else 1)
+
+    def _run(self, ops, stream: int):
+        """Replay a program natively.  With several streams the independent branches of each
+        exchange module (and, in backward, the weight gradients) run concurrently; fork/join and
+        cross-stream dependencies are HIP events inside stl_program_run."""
+        h = self._program(ops)
         if self._side is None:
-            self._side = [torch.cuda.Stream(device=self.dev) for _ in range(self.nstreams - 1)]
-        streams = [main] + self._side
-        e0 = torch.cuda.Event()
-        e0.record(main)
-        for s_ in self._side:
-            s_.wait_event(e0)
-        events = {}
-        for i, (name, args, st_, _, _) in enumerate(ops):
-            s_ = streams[st_]
-            for j in waits[i]:
-                s_.wait_event(events[j])
-            rc = getattr(lib, name)(*args, s_.cuda_stream)
-            if rc != 0:
-                raise RuntimeError(f"{name}: {lib.stl_last_error().decode()}")
-            if i in need:
-                ev = torch.cuda.Event()
-                ev.record(s_)
-                events[i] = ev
-        for s_ in self._side:
-            ev = torch.cuda.Event()
-            ev.record(s_)
-            main.wait_event(ev)
+            self._side = [torch.cuda.Stream(device=self.dev) for _ in range(self.total_streams - 1)]
+            self._stream_arr = (C.c_void_p * self.total_streams)()
+            for i, s_ in enumerate(self._side):
+                self._stream_arr[i + 1] = s_.cuda_stream
+        self._stream_arr[0] = stream
+        rc = self.lib.stl_program_run(h, self._stream_arr)
+        if rc != 0:
+            raise RuntimeError(f"stl_program_run: {self.lib.stl_last_error().decode()}")
 
     def prep_weights(self, stream: int):
         st = self.store

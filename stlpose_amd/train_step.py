@@ -54,7 +54,7 @@ class TrainStep:
         self._partial = torch.zeros(self._nblk, dtype=torch.float64, device=dev)
         # HIP-graph capture of a plan that forks onto >2 streams crashes inside hipStreamEndCapture
         # on ROCm 7.2 ("graphs"); such plans are replayed eagerly on their streams.
-        if self.eng.nstreams > 2:
+        if self.eng.nstreams > 2 or self.eng.wgrad_streams:
             use_graph = False
         self.use_graph = use_graph
         self._g_fb: Optional[torch.cuda.CUDAGraph] = None

@@ -68,9 +68,11 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("tile", ["auto", "explicit"])
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
-@pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_forward_plain_and_stats(case, dt):
+@pytest.mark.parametrize("case", CONV_CASES + [(4, 48, 36, 32, 32, 3, 1), (4, 48, 36, 64, 64, 3, 1), (4, 24, 18, 128, 128, 3, 1),
+                                               (4, 48, 36, 64, 256, 1, 1), (2, 12, 9, 256, 256, 3, 1)])
+def test_conv_forward_plain_and_stats(case, dt, tile):
     code, td, tol = DT[dt]
     B, H, W, Ci, Co, ks, s = case
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -83,9 +85,10 @@ def test_conv_forward_plain_and_stats(case, dt):
     out = torch.full((B * Ho * Wo * Co,), float("nan"), device="cuda", dtype=td)
     st = torch.zeros(capi.NSHARD * 2 * Co, dtype=torch.float64, device="cuda")
     p = capi.Conv()
+    p.shape = -1
     p.dtype, p.B, p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.Co = code, B, H, W, Ci, Ho, Wo, Co
     p.ks, p.stride = ks, s
-    p.TH, p.TW = choose_tile(B, Ho, Wo, s, ks, xt.element_size())
+    p.TH, p.TW = choose_tile(B, Ho, Wo, s, ks, xt.element_size()) if tile == "explicit" else (0, 0)
     p.src.x, p.src.mode = xt.data_ptr(), capi.SRC_PLAIN
     p.w, p.out, p.out_stats = wt.data_ptr(), out.data_ptr(), st.data_ptr()
     capi.call("stl_conv_forward", C.byref(p), stream())
@@ -101,7 +104,8 @@ def test_conv_forward_plain_and_stats(case, dt):
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
-@pytest.mark.parametrize("case", [(2, 24, 16, 32, 32, 3, 1), (2, 24, 18, 32, 64, 3, 2), (2, 8, 6, 128, 64, 1, 1)])
+@pytest.mark.parametrize("case", [(2, 24, 16, 32, 32, 3, 1), (2, 24, 18, 32, 64, 3, 2), (2, 8, 6, 128, 64, 1, 1),
+                                  (4, 48, 36, 64, 64, 3, 1), (4, 24, 18, 128, 128, 3, 1)])
 def test_conv_bn_relu_chain_forward_backward(case, dt):
     """x --BN(relu) on load--> conv --> y ; backward: BN-backward on load, ReLU mask + r1/r2 in the
     data-gradient epilogue, weight gradient slabs.  Reference: torch autograd through
@@ -132,9 +136,10 @@ def test_conv_bn_relu_chain_forward_backward(case, dt):
     yk = torch.empty(B * Ho * Wo * Co, device="cuda", dtype=td)
     st2 = torch.zeros(capi.NSHARD * 2 * Co, dtype=torch.float64, device="cuda")
     p = capi.Conv()
+    p.shape = -1
     p.dtype, p.B, p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.Co = code, B, H, W, Ci, Ho, Wo, Co
     p.ks, p.stride = ks, s
-    p.TH, p.TW = choose_tile(B, Ho, Wo, s, ks, x0t.element_size())
+    p.TH, p.TW = 0, 0
     p.src = bn_src(x0t, st1, g1.detach(), b1.detach(), B * H * W, True)
     p.w, p.out, p.out_stats = wt.data_ptr(), yk.data_ptr(), st2.data_ptr()
     capi.call("stl_conv_forward", C.byref(p), stream())
@@ -171,9 +176,10 @@ def test_conv_bn_relu_chain_forward_backward(case, dt):
     dx = torch.full((B * H * W * Ci,), float("nan"), device="cuda", dtype=td)
     red = torch.zeros(capi.NSHARD * 2 * Ci, dtype=torch.float64, device="cuda")
     d = capi.Conv()
+    d.shape = -1
     d.dtype, d.B, d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.Co = code, B, Ho, Wo, Co, H, W, Ci
     d.ks, d.stride, d.stuff = ks, 1, int(s == 2)
-    d.TH, d.TW = choose_tile(B, H, W, 1, ks, x0t.element_size())
+    d.TH, d.TW = 0, 0
     d.src, d.w, d.out = gs, wb.data_ptr(), dx.data_ptr()
     d.mask_y, d.mask_bn, d.red = x0t.data_ptr(), p.src, red.data_ptr()
     capi.call("stl_conv_forward", C.byref(d), stream())
@@ -345,6 +351,7 @@ def test_optimizers_match_torch():
 
 def test_error_reporting():
     p = capi.Conv()
+    p.shape = -1
     p.dtype, p.ks, p.stride = 0, 5, 1
     with pytest.raises(RuntimeError, match="ks must be 1 or 3"):
         capi.call("stl_conv_forward", C.byref(p), stream())
