@@ -24,6 +24,7 @@ constexpr int PSA = 96;
 
 // debug-only phase stamps (block 0, thread 0; enabled by STL_CONV_STAMPS=1): never read by the kernel
 __device__ long long g_stamps[32];
+__device__ long long g_stamps2[64];  // wave-specialised kernel: [0..23] loader, [32..55] compute (6 stages x 4)
 #define STAMP(i)                                                          \
     do {                                                                  \
         if (k.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); \
@@ -37,6 +38,7 @@ struct ConvK {
     int nchunks, wres;
     int cipad;
     int off_cs, off_cm, off_a, off_b, off_red;
+    int sz_a, sz_b;  // wave-specialised kernel: byte distance between the two LDS buffers (0 = single)
     int TH, TW;
     int dbg;
 };
@@ -63,6 +65,8 @@ __device__ __forceinline__ void store4(void* base, size_t elem, const float* f) 
         stg16((char*)base + elem * 4, pack<float>(f));
     }
 }
+
+#include "conv_common.inc"
 
 // WM x WN waves, MT pixel tiles and NTW channel tiles per wave; NVA staging vectors per thread for
 // the input halo; Q: source is BNBWD (second tensor on load).
@@ -192,34 +196,20 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
             }
         }
     };
+    const float relu_lo = p.src.relu ? 0.f : -INFINITY;
     auto write_lds = [&](const int* go, int k0) {
         const int ch = k0 + a_part * KV;
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
             if (a_rc[i] < 0) continue;
             const bool ok = go[i] >= 0 && ch < p.Ci;
+            const int chc = ok ? ch : 0;
             V16 val = ra[i];
-            if (p.src.mode != STL_SRC_PLAIN) {
-                float f[KV];
-                unpack<T>(val, f);
-                const int chc = ok ? ch : 0;
-                if (!Q) {
-#pragma unroll
-                    for (int j = 0; j < KV; ++j) {
-                        float u = cs[chc + j] * f[j] + cs[k.cipad + chc + j];
-                        f[j] = p.src.relu ? fmaxf(u, 0.f) : u;
-                    }
-                } else {
-                    float q[KV];
-                    unpack<T>(rq[i], q);
-#pragma unroll
-                    for (int j = 0; j < KV; ++j)
-                        f[j] = cs[chc + j] * f[j] + cs[k.cipad + chc + j] * q[j] + cs[2 * k.cipad + chc + j];
-                }
-                val = pack<T>(f);
-            }
-            const uint32_t keep = ok ? 0xFFFFFFFFu : 0u;  // zero padding applies AFTER the transform
-            val.w[0] &= keep, val.w[1] &= keep, val.w[2] &= keep, val.w[3] &= keep;
+            if (Q)
+                val = xform_bnbwd<T>(val, rq[i], cs + chc, cs + k.cipad + chc, cs + 2 * k.cipad + chc);
+            else if (p.src.mode != STL_SRC_PLAIN)
+                val = xform_bn<T>(val, cs + chc, cs + k.cipad + chc, relu_lo);
+            mask16(val, ok);  // zero padding applies AFTER the transform
             const int v = tid + i * NTHR;
             *reinterpret_cast<V16*>(sA + (v >> 2) * PSA + (v & 3) * 16) = val;
         }
@@ -227,9 +217,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 #pragma unroll
             for (int i = 0; i < NVB; ++i) {
                 const bool ok = b_g[i] >= 0 && (k0 + ((tid + i * NTHR) & 3) * KV) < p.Ci;
-                const uint32_t keep = ok ? 0xFFFFFFFFu : 0u;
                 V16 val = rb[i];
-                val.w[0] &= keep, val.w[1] &= keep, val.w[2] &= keep, val.w[3] &= keep;
+                mask16(val, ok);
                 if (tid + i * NTHR < BCO * TAPS * 4) *reinterpret_cast<V16*>(sB + b_l[i]) = val;
             }
         }
@@ -247,11 +236,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     }
 
     // statistics accumulators: this lane's 4 channels of each of its NTW channel tiles
-    float s0[NTW][4], s1[NTW][4];
+    f2v s0[NTW][2], s1[NTW][2];
 #pragma unroll
     for (int ni = 0; ni < NTW; ++ni)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s0[ni][r] = s1[ni][r] = 0.f;
+        for (int h = 0; h < 2; ++h) s0[ni][h] = f2v{0.f, 0.f}, s1[ni][h] = f2v{0.f, 0.f};
 
     const int xcd = blockIdx.x & 7, lx = blockIdx.x >> 3, nx = gridDim.x >> 3;
     const int T8 = (k.npt + 7) >> 3;
@@ -291,18 +280,27 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
         }
         issue(a_go, chn * CK, have_n);  // next stage's loads land during the MFMAs below
         if (ch0 == 0) STAMP(6);
+        {  // fragment reads of tap t+1 are issued before the MFMAs of tap t (static double buffer)
+            V16 wf[2][NTW], xf[2][MT];
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int toff = ((tap / KS) * k.HC + (tap % KS)) * PSA;
-            V16 wf[NTW], xf[MT];
+            for (int ni = 0; ni < NTW; ++ni) wf[0][ni] = *reinterpret_cast<const V16*>(sB + woff + ni * 16 * ROWB);
 #pragma unroll
-            for (int ni = 0; ni < NTW; ++ni) wf[ni] = *reinterpret_cast<const V16*>(sB + woff + ni * 16 * ROWB + tap * 64);
+            for (int mi = 0; mi < MT; ++mi) xf[0][mi] = *reinterpret_cast<const V16*>(sA + xoff[mi]);
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi) xf[mi] = *reinterpret_cast<const V16*>(sA + xoff[mi] + toff);
+            for (int tap = 0; tap < TAPS; ++tap) {
+                if (tap + 1 < TAPS) {
+                    const int toff = (((tap + 1) / KS) * k.HC + ((tap + 1) % KS)) * PSA;
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
+                    for (int ni = 0; ni < NTW; ++ni)
+                        wf[(tap + 1) & 1][ni] = *reinterpret_cast<const V16*>(sB + woff + ni * 16 * ROWB + (tap + 1) * 64);
 #pragma unroll
-                for (int ni = 0; ni < NTW; ++ni) mma16<T>(acc[mi][ni], wf[ni], xf[mi]);
+                    for (int mi = 0; mi < MT; ++mi) xf[(tap + 1) & 1][mi] = *reinterpret_cast<const V16*>(sA + xoff[mi] + toff);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NTW; ++ni) mma16<T>(acc[mi][ni], wf[tap & 1][ni], xf[tap & 1][mi]);
+            }
         }
         __syncthreads();  // everyone is done with sA/sB of this stage
         if (ch0 == 0) STAMP(7);
@@ -320,64 +318,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
                     pok = (b < p.B) && (oy < p.Ho) && (c < p.Wo);
                 }
                 const size_t pix = pok ? (((size_t)b * p.Ho + oy) * p.Wo + c) * p.Co : 0;
-                // issue every load of this pixel tile first (one round trip, not one per element)
-                float ad[NTW][4], my[NTW][4];
-                bool okv[NTW];
-                size_t eov[NTW];
-#pragma unroll
-                for (int ni = 0; ni < NTW; ++ni) {
-                    const int co = n0 + (wn * NTW + ni) * 16 + 4 * g;
-                    okv[ni] = pok && co < p.Co;
-                    eov[ni] = okv[ni] ? pix + co : 0;  // invalid lanes read element 0, store nothing
-                }
-                if (p.addend) {
-#pragma unroll
-                    for (int ni = 0; ni < NTW; ++ni) load4<T>(p.addend, eov[ni], ad[ni]);
-                }
-                if (p.mask_y) {
-#pragma unroll
-                    for (int ni = 0; ni < NTW; ++ni) load4<T>(p.mask_y, eov[ni], my[ni]);
-                }
-#pragma unroll
-                for (int ni = 0; ni < NTW; ++ni) {
-                    const int cl = (wn * NTW + ni) * 16 + 4 * g;  // channel within the block's BCO
-                    const int co = n0 + cl;
-                    const bool ok = okv[ni];
-                    float f[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) f[r] = acc[mi][ni][r];
-                    if (p.bias) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) f[r] += p.bias[ok ? co + r : 0];
-                    }
-                    if (p.addend) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) f[r] += ad[ni][r];
-                    }
-                    float yh[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (p.mask_y) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            if (p.mask_bn.relu && !(cm[cl + r] * my[ni][r] + cm[BCO + cl + r] > 0.f)) f[r] = 0.f;
-                            yh[r] = (my[ni][r] - cm[2 * BCO + cl + r]) * cm[3 * BCO + cl + r];
-                        }
-                    }
-                    if (p.out_relu) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) f[r] = fmaxf(f[r], 0.f);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) f[r] = ok ? round_to<T>(f[r]) : 0.f;
-                    if (p.out_stats) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) s0[ni][r] += f[r], s1[ni][r] += f[r] * f[r];
-                    } else if (p.red) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) s0[ni][r] += f[r], s1[ni][r] += f[r] * yh[r];
-                    }
-                    if (ok) store4<T>(p.out, eov[ni], f);
-                    acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+                epilogue_tile<T, NTW, BCO>(p, acc[mi], cm, pok, pix, n0, wn * NTW * 16, g, s0, s1);
             }
         }
         if (last_chunk) STAMP(9);
@@ -388,16 +329,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     // then the WM waves of a channel column through LDS, then one fp64 atomic per channel
     double* dst = p.out_stats ? p.out_stats : p.red;
     if (dst) {
-#pragma unroll
-        for (int ni = 0; ni < NTW; ++ni)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s0[ni][r] += __shfl_xor(s0[ni][r], o);
-                    s1[ni][r] += __shfl_xor(s1[ni][r], o);
-                }
-            }
+        xor_reduce_stats<NTW>(s0, s1);
         float* red = reinterpret_cast<float*>(smem + k.off_red);  // [WM][2][BCO]
         __syncthreads();
         if (r16 == 0) {
@@ -406,8 +338,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int cl = (wn * NTW + ni) * 16 + 4 * g + r;
-                    red[(wm * 2 + 0) * BCO + cl] = s0[ni][r];
-                    red[(wm * 2 + 1) * BCO + cl] = s1[ni][r];
+                    red[(wm * 2 + 0) * BCO + cl] = s0[ni][r >> 1][r & 1];
+                    red[(wm * 2 + 1) * BCO + cl] = s1[ni][r >> 1][r & 1];
                 }
         }
         __syncthreads();
@@ -422,6 +354,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     }
     STAMP(11);
 }
+
+#include "conv_ws.inc"
 
 template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, int OCC = 1>
 int launch(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
@@ -439,10 +373,15 @@ int launch(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
 // block shapes: 0 = 128 px x 64 co (4 waves), 1 = 512 px x 32 co, 2 = 256 px x 64 co, 3 = 256 px x 128 co (8 waves),
 // 4 = 128 px x 32 co (4 waves, <=128 VGPRs, <=40 KB LDS: four blocks per CU hide each other's latency)
 struct Shape {
-    int px, co, thr;
+    int px, co, thr;   // pixels / output channels per block, threads
+    int ws;            // 1: wave-specialised kernel (4 loader + 4 compute waves, double-buffered LDS)
+    int lthr, nva_max; // threads that stage the halo, max staging vectors per such thread
 };
-constexpr int NSHAPES = 5;
-constexpr Shape SHAPES[NSHAPES] = {{128, 64, 256}, {512, 32, 512}, {256, 64, 512}, {256, 128, 512}, {128, 32, 256}};
+// 0..4: uniform-wave kernel (conv_core_kernel); 5..7: wave-specialised kernel (conv_ws_kernel)
+constexpr int NSHAPES = 8;
+constexpr Shape SHAPES[NSHAPES] = {{128, 64, 256, 0, 256, 9}, {512, 32, 512, 0, 512, 6}, {256, 64, 512, 0, 512, 3},
+                                   {256, 128, 512, 0, 512, 3}, {128, 32, 256, 0, 256, 6},
+                                   {512, 32, 512, 1, 256, 10}, {256, 64, 512, 1, 256, 6}, {128, 64, 512, 1, 256, 9}};
 
 template <typename T, int KS, bool Q>
 int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
@@ -464,6 +403,16 @@ int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStrea
             if (nva <= 3) return launch<T, KS, 4, 1, 2, 2, 3, Q, 4>(k, grid, lds, st);
             if (nva <= 6) return launch<T, KS, 4, 1, 2, 2, 6, Q, 3>(k, grid, lds, st);
             break;
+        case 5:
+            if (nva <= 10) return launch_ws<T, KS, 8, 2, 10, Q>(k, grid, lds, st);
+            break;
+        case 6:
+            if (nva <= 6) return launch_ws<T, KS, 4, 4, 6, Q>(k, grid, lds, st);
+            break;
+        case 7:
+            if (nva <= 3) return launch_ws<T, KS, 2, 4, 3, Q>(k, grid, lds, st);
+            if (nva <= 9) return launch_ws<T, KS, 2, 4, 9, Q>(k, grid, lds, st);
+            break;
     }
     return stl_set_error("conv: no kernel variant for block shape %d with %d staging vectors per thread", shape, nva);
 }
@@ -479,21 +428,27 @@ size_t lds_bytes(const stl_conv& p, int shape, int TH, int TW, int ck, ConvK* ou
     const int taps = p.ks * p.ks, seff = p.stride;
     const int HR = (TH - 1) * seff + p.ks, HC = (TW - 1) * seff + p.ks;
     const int nchunks = ceil_div(p.Ci, ck), cipad = nchunks * ck;
-    const int bco = SHAPES[shape].co;
+    const int bco = SHAPES[shape].co, ws = SHAPES[shape].ws;
     int off = 3 * cipad * 4;
     const int off_cm = off;
     off += 4 * bco * 4;
     off = (off + 15) & ~15;
     const int off_a = off;
-    off += ((HR * HC * PSA) + 15) & ~15;
+    const int sz_a = ((HR * HC * PSA) + 15) & ~15;
+    off += sz_a * (ws ? 2 : 1);
     const int off_b = off;
-    off += bco * (taps * 64 + 32);
+    const int sz_b = bco * (taps * 64 + 32);
+    // wave-specialised kernel: keep the whole filter slab (all chunks) resident when it fits
+    const bool resident = nchunks == 1 || (ws && (size_t)off + (size_t)sz_b * nchunks <= 150 * 1024);
+    off += resident ? sz_b * nchunks : sz_b * (ws ? 2 : 1);
     const int off_red = off_a;  // reused after the last stage
     const int red = 8 * 2 * bco * 4;
     if (off - off_a < red) off = off_a + red;
     if (out) {
         out->HR = HR, out->HC = HC, out->HP = HR * HC, out->nchunks = nchunks, out->cipad = cipad;
         out->off_cs = 0, out->off_cm = off_cm, out->off_a = off_a, out->off_b = off_b, out->off_red = off_red;
+        out->sz_a = ws ? sz_a : 0, out->sz_b = (ws && !resident) ? sz_b : 0;
+        out->wres = resident ? 1 : 0;
     }
     return (size_t)off;
 }
@@ -503,18 +458,19 @@ Plan choose_plan(const stl_conv& p, int ck) {
     const int vrows = p.B * (p.Ho + 1);
     for (int shape = 0; shape < NSHAPES; ++shape) {
         const Shape sh = SHAPES[shape];
-        if (shape != 0 && shape != 4 && p.stride == 2) continue;  // stride-2 halos only fit the small blocks
-        if (shape == 1 && p.Co > 32) continue;
-        if (shape == 2 && p.Co > 64 && p.Co % 64 != 0 && false) continue;
+        if (sh.px > 128 && p.stride == 2) continue;  // stride-2 halos only fit the small blocks
+        if ((shape == 1 || shape == 5) && p.Co > 32) continue;
         if (shape == 3 || shape == 4) continue;  // measured slower (register spills); reachable via STL_CONV_SHAPE only
+        if (sh.ws != (getenv("STL_CONV_WS") ? atoi(getenv("STL_CONV_WS")) : 1)) continue;  // kernel family
         const int nblk_co = ceil_div(p.Co, sh.co);
-        for (int tw = (p.Wo < 4 ? p.Wo : 4); tw <= p.Wo && tw <= sh.px; ++tw) {
-            int th = sh.px / tw;
+        for (int tw = (p.Wo < 4 ? p.Wo : 4); tw <= p.Wo && tw <= sh.px; ++tw)
+          for (int frac = 4; frac >= 1; --frac) {
+            int th = (sh.px / tw) * frac / 4;
             if (th > vrows) th = vrows;
             if (th < 1) continue;
             const int hr = (th - 1) * p.stride + p.ks, hc = (tw - 1) * p.stride + p.ks;
-            const int nva = ceil_div(hr * hc * 4, sh.thr);
-            if ((shape == 0 && nva > 9) || (shape == 1 && nva > 6) || ((shape == 2 || shape == 3) && nva > 3) || (shape == 4 && nva > 6)) continue;
+            const int nva = ceil_div(hr * hc * 4, sh.lthr);
+            if (nva > sh.nva_max) continue;
             const size_t lds = lds_bytes(p, shape, th, tw, ck, nullptr);
             if (shape == 4 && lds > 40 * 1024 && nva <= 3) continue;  // keep four blocks per CU
             if (lds > 158 * 1024) continue;
@@ -538,6 +494,9 @@ Plan choose_plan(const stl_conv& p, int ck) {
 extern "C" int stl_debug_conv_stamps(long long* host12) {
     return hipMemcpyFromSymbol(host12, HIP_SYMBOL(g_stamps), 12 * sizeof(long long)) == hipSuccess ? 0 : stl_set_error("stamps: copy failed");
 }
+extern "C" int stl_debug_conv_stamps2(long long* host64) {
+    return hipMemcpyFromSymbol(host64, HIP_SYMBOL(g_stamps2), 64 * sizeof(long long)) == hipSuccess ? 0 : stl_set_error("stamps: copy failed");
+}
 
 extern "C" int stl_conv_plan(stl_conv* pp) {
     stl_conv& p = *pp;
@@ -547,7 +506,7 @@ extern "C" int stl_conv_plan(stl_conv* pp) {
     Plan plan = choose_plan(p, ck);
     if (const char* e = getenv("STL_CONV_SHAPE")) {  // tuning knob: force a block shape where legal
         const int f = atoi(e);
-        if (f >= 0 && f < NSHAPES && !(f != 0 && f != 4 && p.stride == 2)) {
+        if (f >= 0 && f < NSHAPES && !(SHAPES[f].px > 128 && p.stride == 2)) {
             Plan best{-1, 0, 0, 0, 1e300};
             const int vrows = p.B * (p.Ho + 1);
             const Shape sh = SHAPES[f];
@@ -555,8 +514,8 @@ extern "C" int stl_conv_plan(stl_conv* pp) {
                 int th = sh.px / tw;
                 if (th > vrows) th = vrows;
                 const int hr = (th - 1) * p.stride + p.ks, hc = (tw - 1) * p.stride + p.ks;
-                const int nva = ceil_div(hr * hc * 4, sh.thr);
-                if ((f == 0 && nva > 9) || ((f == 1 || f == 4) && nva > 6) || ((f == 2 || f == 3) && nva > 3)) continue;
+                const int nva = ceil_div(hr * hc * 4, sh.lthr);
+                if (nva > sh.nva_max) continue;
                 const size_t l = lds_bytes(p, f, th, tw, ck, nullptr);
                 if (l > 158 * 1024) continue;
                 const double waste = (double)ceil_div(vrows, th) * th * ceil_div(p.Wo, tw) * tw * (double)hr * hc / (th * tw);
@@ -614,8 +573,8 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     }
     {
         const Shape shp = SHAPES[plan.shape];
-        const int nv = ceil_div(((plan.TH - 1) * p.stride + p.ks) * ((plan.TW - 1) * p.stride + p.ks) * 4, shp.thr);
-        STL_CHECK(nv <= (plan.shape == 0 ? 9 : (plan.shape == 1 || plan.shape == 4) ? 6 : 3), "conv: tile %dx%d has too large a halo for block shape %d", plan.TH, plan.TW, plan.shape);
+        const int nv = ceil_div(((plan.TH - 1) * p.stride + p.ks) * ((plan.TW - 1) * p.stride + p.ks) * 4, shp.lthr);
+        STL_CHECK(nv <= shp.nva_max, "conv: tile %dx%d has too large a halo for block shape %d", plan.TH, plan.TW, plan.shape);
     }
     ConvK k;
     k.p = p;
@@ -626,17 +585,16 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     k.TH = plan.TH, k.TW = plan.TW;
     const size_t lds = lds_bytes(p, plan.shape, plan.TH, plan.TW, ck, &k);
     STL_CHECK(lds <= 160 * 1024, "conv: tile needs %zu B of LDS (>160 KiB)", lds);
-    k.wres = k.nchunks == 1;
     const int vrows = p.B * (p.Ho + 1);
     k.tiles_c = ceil_div(p.Wo, plan.TW);
     k.npt = ceil_div(vrows, plan.TH) * k.tiles_c;
     const Shape sh = SHAPES[plan.shape];
     int gx = ceil_div(k.npt, 8) * 8;
-    int cap = sh.thr == 512 ? 512 : (plan.shape == 4 ? 2048 : 1024);
+    int cap = sh.ws ? 256 : (sh.thr == 512 ? 512 : (plan.shape == 4 ? 2048 : 1024));
     if (const char* e = getenv("STL_CONV_GRID_CAP")) cap = atoi(e) > 0 ? (atoi(e) + 7) / 8 * 8 : cap;
     if (gx > cap) gx = cap;
     dim3 grid(gx, ceil_div(p.Co, sh.co));
-    const int nva = ceil_div(k.HP * 4, sh.thr);
+    const int nva = ceil_div(k.HP * 4, sh.lthr);
     if (getenv("STL_CONV_DEBUG"))
         fprintf(stderr, "[stl conv] %dx%d Ci%d Co%d ks%d s%d: shape=%d tile=%dx%d npt=%d grid=(%d,%d) lds=%zu nva=%d nchunks=%d\n", p.Ho,
                 p.Wo, p.Ci, p.Co, p.ks, p.stride, plan.shape, plan.TH, plan.TW, k.npt, gx, grid.y, lds, nva, k.nchunks);
