@@ -116,13 +116,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)  # rehearsal on a one-GPU box: several ranks share the card
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("STL_DIST_BACKEND", "nccl")  # "nccl" == RCCL on ROCm; gloo only for rehearsal
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         pg = dist.group.WORLD
 
     from stlpose_amd import PoseHighResolutionNet

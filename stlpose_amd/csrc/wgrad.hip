@@ -13,6 +13,8 @@
 
 namespace {
 
+#include "conv_common.inc"
+
 struct WgK {
     stl_wgrad p;
     int tiles_c, npt, HR, HC, HP, PI, pad, taps;
@@ -172,21 +174,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
             rhv[i] = ldg16((const char*)p.h.x + off * sizeof(T));
         }
     };
+    const float relu_lo = p.h.relu ? 0.f : -INFINITY;
     auto write_lds = [&]() {
         const int cl = g_part * KV;
 #pragma unroll
         for (int i = 0; i < NVG; ++i) {
             V16 val = rgv[i];
-            if (GQ) {
-                float f[KV], q[KV];
-                unpack<T>(val, f);
-                unpack<T>(rgq[i], q);
-#pragma unroll
-                for (int j = 0; j < KV; ++j) f[j] = cgc[cl + j] * f[j] + cgc[32 + cl + j] * q[j] + cgc[64 + cl + j];
-                val = pack<T>(f);
-            }
-            const uint32_t keep = g_go[i] >= 0 ? 0xFFFFFFFFu : 0u;
-            val.w[0] &= keep, val.w[1] &= keep, val.w[2] &= keep, val.w[3] &= keep;
+            if (GQ) val = xform_bnbwd<T>(val, rgq[i], cgc + cl, cgc + 32 + cl, cgc + 64 + cl);
+            mask16(val, g_go[i] >= 0);
             const int v = tid + i * 256;
             *reinterpret_cast<V16*>(sG + (v / VPX) * k.psg + g_part * 16) = val;
         }
@@ -194,18 +189,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
         for (int i = 0; i < NVH; ++i) {
             if (h_rc[i] < 0) continue;
             V16 val = rhv[i];
-            if (p.h.mode == STL_SRC_BN) {
-                float f[KV];
-                unpack<T>(val, f);
-#pragma unroll
-                for (int j = 0; j < KV; ++j) {
-                    float u = chc[cl + j] * f[j] + chc[32 + cl + j];
-                    f[j] = p.h.relu ? fmaxf(u, 0.f) : u;
-                }
-                val = pack<T>(f);
-            }
-            const uint32_t keep = h_go[i] >= 0 ? 0xFFFFFFFFu : 0u;
-            val.w[0] &= keep, val.w[1] &= keep, val.w[2] &= keep, val.w[3] &= keep;
+            if (p.h.mode == STL_SRC_BN) val = xform_bn<T>(val, chc + cl, chc + 32 + cl, relu_lo);
+            mask16(val, h_go[i] >= 0);
             const int v = tid + i * 256;
             *reinterpret_cast<V16*>(sH + (v / VPX) * k.psh + g_part * 16) = val;
         }

@@ -386,7 +386,8 @@ class Engine:
                 wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32)
                 npt = math.ceil(x.B * (y.H + 1) / wg.TH) * math.ceil(y.W / wg.TW)
                 chunks = math.ceil(y.C / 32) * math.ceil(x.C / 32)
-                wg.nsplit = max(1, min(npt, 256 // chunks if chunks <= 256 else 1))
+                budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS", "256"))
+                wg.nsplit = max(1, min(npt, budget // chunks if chunks <= budget else 1))
                 wg.h = self._src(x)
                 wg.g = g
                 nel = y.C * kks * kks * x.C
