@@ -42,7 +42,7 @@ def synth_batch(B, H, W, rank, device, sigma=3.0, joints=17):
 
 def time_dominant_kernel(ts):
     """The dominant kernel by GPU time (profiles/: ~25 % of the step) is the 3x3 stride-1 weight
-    gradient `wgrad_kernel<bf16,3,NVH=3,GQ=1>` (BatchNorm-backward applied on load).  Every launch
+    gradient `wgrad_kernel<bf16,KS=3,GQ=1>` (BatchNorm-backward applied on load).  Every launch
     of that instantiation in one backward pass is timed on its own with HIP events on the launch
     stream; achieved = sum of algorithmic FLOPs / sum of durations."""
     from stlpose_amd import capi
@@ -68,7 +68,7 @@ def time_dominant_kernel(ts):
     flops = sum(2.0 * d.B * d.Ho * d.Wo * d.Co * d.Ci * 9 for _, _, d in evs)
     esz = 2 if eng.dtype == capi.BF16 else 4
     bytes_alg = sum((d.B * d.Hi * d.Wi * d.Ci + 2 * d.B * d.Ho * d.Wo * d.Co) * esz + d.nsplit * d.Co * d.Ci * 9 * 4 for _, _, d in evs)
-    return dict(kernel="wgrad_kernel<bf16,KS=3,NVH=3,GQ=1> (3x3 stride-1 weight gradient, BN-backward on load)",
+    return dict(kernel="wgrad_kernel<bf16,KS=3,GQ=1,TPX=128|256> (3x3 stride-1 weight gradient, BN-backward on load)",
                 launches=len(evs), ms=tot_ms / len(evs), tflops=flops / tot_ms / 1e9, gbs=bytes_alg / tot_ms / 1e6)
 
 

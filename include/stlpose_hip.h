@@ -78,6 +78,7 @@ int stl_conv_plan(stl_conv* p);
 /* Debug: phase time stamps (100 MHz ticks) of block 0 of the last conv launched with STL_CONV_STAMPS=1. */
 int stl_debug_conv_stamps(long long* host12);
 int stl_debug_conv_stamps2(long long* host64);
+int stl_debug_wgrad_stamps(long long* host16);
 
 /* Weight gradient of the same convolution (aten::convolution_backward, weight part).
  * partial[s][co][tap][ci] (fp32) for s < nsplit; summed later by stl_reduce_slabs.

@@ -96,6 +96,7 @@ SIGNATURES = {
     "stl_conv_plan": [C.POINTER(Conv)],
     "stl_debug_conv_stamps": [vp],
     "stl_debug_conv_stamps2": [vp],
+    "stl_debug_wgrad_stamps": [vp],
     "stl_conv_wgrad": [C.POINTER(Wgrad), vp],
     "stl_fuse_forward": [C.POINTER(Fuse), vp],
     "stl_fuse_backward": [C.POINTER(FuseBwd), vp],

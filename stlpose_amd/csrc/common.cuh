@@ -156,6 +156,70 @@ __device__ __forceinline__ void src_consts(const stl_src& s, int c, int C, float
     }
 }
 
+// Two-phase variant: src_raw_load only ISSUES the loads of one channel's statistics (so that they
+// queue ahead of a burst of tile loads), src_raw_finish does the arithmetic of src_consts.
+struct SrcRaw {
+    double st[2 * STL_NSHARD], rs[2 * STL_NSHARD];
+    float g, b, rm, rv;
+};
+__device__ __forceinline__ void src_raw_load(const stl_src& s, int c, int C, SrcRaw& r) {
+    if (s.mode == STL_SRC_PLAIN) return;
+    r.g = s.gamma[c];
+    if (s.stats) {
+#pragma unroll
+        for (int k = 0; k < STL_NSHARD; ++k) {
+            r.st[2 * k] = s.stats[(size_t)k * 2 * C + c];
+            r.st[2 * k + 1] = s.stats[(size_t)k * 2 * C + C + c];
+        }
+    } else {
+        r.rm = s.rmean[c], r.rv = s.rvar[c];
+    }
+    if (s.mode == STL_SRC_BN) {
+        r.b = s.beta[c];
+    } else {
+#pragma unroll
+        for (int k = 0; k < STL_NSHARD; ++k) {
+            r.rs[2 * k] = s.rstats[(size_t)k * 2 * C + c];
+            r.rs[2 * k + 1] = s.rstats[(size_t)k * 2 * C + C + c];
+        }
+    }
+}
+__device__ __forceinline__ void src_raw_finish(const stl_src& s, const SrcRaw& r, float& ca, float& cb, float& cc) {
+    if (s.mode == STL_SRC_PLAIN) {
+        ca = 1.f, cb = 0.f, cc = 0.f;
+        return;
+    }
+    float mean, rstd;
+    if (s.stats) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < STL_NSHARD; ++k) s0 += r.st[2 * k], s1 += r.st[2 * k + 1];
+        double m = s0 * (double)s.inv_count;
+        double var = s1 * (double)s.inv_count - m * m;
+        if (var < 0.0) var = 0.0;
+        mean = (float)m;
+        rstd = (float)(1.0 / sqrt(var + (double)s.eps));
+    } else {
+        mean = r.rm;
+        rstd = (float)(1.0 / sqrt((double)r.rv + (double)s.eps));
+    }
+    if (s.mode == STL_SRC_BN) {
+        ca = r.g * rstd;
+        cb = r.b - mean * ca;
+        cc = 0.f;
+    } else {
+        double r1 = 0.0, r2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < STL_NSHARD; ++k) r1 += r.rs[2 * k], r2 += r.rs[2 * k + 1];
+        const float c1 = (float)(r1 * (double)s.inv_count);
+        const float c2 = (float)(r2 * (double)s.inv_count);
+        const float al = r.g * rstd;
+        ca = al;
+        cb = -al * rstd * c2;
+        cc = al * (mean * rstd * c2 - c1);
+    }
+}
+
 // block-wide helpers ---------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

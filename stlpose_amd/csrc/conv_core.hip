@@ -84,6 +84,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     const int n0 = blockIdx.y * BCO;
 
     STAMP(0);
+    if (k.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[12] = __builtin_amdgcn_s_memtime();
     float* cs = reinterpret_cast<float*>(smem + k.off_cs);  // [3][cipad] source transform
     float* cm = reinterpret_cast<float*>(smem + k.off_cm);  // [4][BCO]   mask BN: a, b, mean, rstd
     char* sA = smem + k.off_a;
@@ -353,6 +354,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
         }
     }
     STAMP(11);
+    if (k.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[13] = __builtin_amdgcn_s_memtime();
 }
 
 #include "conv_ws.inc"
@@ -460,8 +462,17 @@ Plan choose_plan(const stl_conv& p, int ck) {
         const Shape sh = SHAPES[shape];
         if (sh.px > 128 && p.stride == 2) continue;  // stride-2 halos only fit the small blocks
         if ((shape == 1 || shape == 5) && p.Co > 32) continue;
-        if (shape == 3 || shape == 4) continue;  // measured slower (register spills); reachable via STL_CONV_SHAPE only
-        if (sh.ws != (getenv("STL_CONV_WS") ? atoi(getenv("STL_CONV_WS")) : 1)) continue;  // kernel family
+        if (shape == 3) continue;  // 256x128 block spills registers; reachable via STL_CONV_SHAPE only
+        // 128 px x 32 co blocks (four per CU) win in isolation for the C<=32 3x3 layers (21.7 vs 28.2 us)
+        const bool c32 = !getenv("STL_CONV_NO_C32_SHAPE4") && p.Co <= 32 && p.stride == 1 && p.ks == 3;
+        if (shape == 4 && !c32) continue;
+        if (c32 && shape != 4) continue;
+        // kernel family: measured on MI355X (tools/conv_probe2.py) the wave-specialised kernel wins for
+        // stride-2 convs and for the small, deep maps (Co >= 256), the uniform kernel elsewhere
+        const int want_ws = getenv("STL_CONV_WS") ? atoi(getenv("STL_CONV_WS"))
+                                                  : ((p.stride == 2 || (p.ks == 3 && p.Co >= 256 && (int64_t)p.B * p.Ho * p.Wo <= 8192)) ? 1 : 0);
+        if (sh.ws != want_ws) continue;
+        if (want_ws && !getenv("STL_CONV_WS") && shape != 7) continue;
         const int nblk_co = ceil_div(p.Co, sh.co);
         for (int tw = (p.Wo < 4 ? p.Wo : 4); tw <= p.Wo && tw <= sh.px; ++tw)
           for (int frac = 4; frac >= 1; --frac) {
@@ -492,7 +503,7 @@ Plan choose_plan(const stl_conv& p, int ck) {
 }  // namespace
 
 extern "C" int stl_debug_conv_stamps(long long* host12) {
-    return hipMemcpyFromSymbol(host12, HIP_SYMBOL(g_stamps), 12 * sizeof(long long)) == hipSuccess ? 0 : stl_set_error("stamps: copy failed");
+    return hipMemcpyFromSymbol(host12, HIP_SYMBOL(g_stamps), 14 * sizeof(long long)) == hipSuccess ? 0 : stl_set_error("stamps: copy failed");
 }
 extern "C" int stl_debug_conv_stamps2(long long* host64) {
     return hipMemcpyFromSymbol(host64, HIP_SYMBOL(g_stamps2), 64 * sizeof(long long)) == hipSuccess ? 0 : stl_set_error("stamps: copy failed");
@@ -590,7 +601,7 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     k.npt = ceil_div(vrows, plan.TH) * k.tiles_c;
     const Shape sh = SHAPES[plan.shape];
     int gx = ceil_div(k.npt, 8) * 8;
-    int cap = sh.ws ? 256 : (sh.thr == 512 ? 512 : (plan.shape == 4 ? 2048 : 1024));
+    int cap = sh.ws ? 256 : (sh.thr == 512 ? 512 : 1024);
     if (const char* e = getenv("STL_CONV_GRID_CAP")) cap = atoi(e) > 0 ? (atoi(e) + 7) / 8 * 8 : cap;
     if (gx > cap) gx = cap;
     dim3 grid(gx, ceil_div(p.Co, sh.co));

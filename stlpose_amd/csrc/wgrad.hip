@@ -15,12 +15,24 @@ namespace {
 
 #include "conv_common.inc"
 
+// debug-only phase stamps (block 0, thread 0; STL_CONV_STAMPS=1): never read by the kernel
+__device__ long long g_wstamps[16];
+#define WSTAMP(i)                                                                                   \
+    do {                                                                                            \
+        if (k.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_wstamps[i] = wall_clock64(); \
+    } while (0)
+
 struct WgK {
     stl_wgrad p;
+    int dbg;
     int tiles_c, npt, HR, HC, HP, PI, pad, taps;
     int psg, psh;  // LDS bytes per pixel (32 channels + 16 B pad)
     int off_cg, off_ch, off_g, off_h;
+    float r_TW, r_HC, r_tc, r_vp, r_PI;  // reciprocals for fdiv
 };
+
+// floor(m / d) for 0 <= m < 2^21 with r = 1/d (d <= 2^10): exact, ~4 instructions instead of ~40
+__device__ __forceinline__ int fdiv(int m, float r) { return (int)(((float)m + 0.5f) * r); }
 
 template <typename T>
 __device__ __forceinline__ V16 frag_tr(const char* base, const int* rowoff, int colbyte, int lane);
@@ -50,32 +62,23 @@ __device__ __forceinline__ V16 frag_tr<float>(const char* base, const int* rowof
 }
 
 // NVH: h (input halo) staging vectors per thread; GQ: g is BNBWD (second tensor on load)
-template <typename T, int KS, int NVH, bool GQ>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
+// OCC: blocks per CU the register budget is sized for (2 only where it does not spill)
+template <typename T, int KS, int NVH, bool GQ, int TPX, int OCC>
+__global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgK k) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KV = ET<T>::KV, TAPS = KS * KS;
     constexpr int KSTEP = 4 * KV;               // pixels per MFMA K step (32 bf16 / 16 f32)
     constexpr int NR = sizeof(T) == 2 ? 2 : 4;  // row offsets a lane needs per fragment
     constexpr int VPX = 32 / KV;                // 16-byte vectors per pixel (32 channels)
-    constexpr int NVG = 128 * VPX / 256;        // g staging vectors per thread
+    constexpr int NVG = TPX * VPX / 256;        // g staging vectors per thread
     const stl_wgrad& p = k.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
     const int co0 = blockIdx.y * 32, ci0 = blockIdx.z * 32;
+    WSTAMP(0);
     float* cgc = reinterpret_cast<float*>(smem + k.off_cg);  // [3][32]
     float* chc = reinterpret_cast<float*>(smem + k.off_ch);  // [2][32]
     char* sG = smem + k.off_g;
     char* sH = smem + k.off_h;
-
-    if (tid < 32) {
-        float a = 0.f, b = 0.f, c = 0.f;
-        if (co0 + tid < p.Co) src_consts(p.g, co0 + tid, p.Co, a, b, c);
-        cgc[tid] = a, cgc[32 + tid] = b, cgc[64 + tid] = c;
-    } else if (tid < 64) {
-        const int t = tid - 32;
-        float a = 0.f, b = 0.f, c = 0.f;
-        if (ci0 + t < p.Ci) src_consts(p.h, ci0 + t, p.Ci, a, b, c);
-        chc[t] = a, chc[32 + t] = b;
-    }
 
     const int tilepx = p.TH * p.TW;
     const int vpitch = p.Ho + 1;
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
         const int m = (tid + i * 256) / VPX;
         g_yx[i] = -1;
         if (m < tilepx) {
-            const int ty = m / p.TW;
+            const int ty = fdiv(m, k.r_TW);
             g_yx[i] = (ty << 16) | (m - ty * p.TW);
         }
     }
@@ -99,15 +102,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
         const int v = tid + i * 256;
         h_rc[i] = -1;
         if (v < k.HP * VPX) {
-            const int hp = v / VPX, hr = hp / k.HC;
+            const int hp = v / VPX, hr = fdiv(hp, k.r_HC);
             h_rc[i] = (hr << 16) | (hp - hr * k.HC);
         }
     }
     const bool g_chok = (co0 + g_part * KV) < p.Co, h_chok = (ci0 + g_part * KV) < p.Ci;
 
     // ---- MFMA-side offsets for this wave's K steps (tile geometry is the same for every tile)
-    // at most 2 K steps per wave (128 px / KSTEP / 4 waves: 1 for bf16, 2 for fp32)
-    constexpr int NKS = (128 / KSTEP + 3) / 4;
+    // K steps per wave: TPX px / KSTEP / 4 waves (128 px: 1 for bf16, 2 for fp32; 256 px bf16: 2)
+    constexpr int NKS = (TPX / KSTEP + 3) / 4;
     int rg[NKS][NR], rh[NKS][NR];
 #pragma unroll
     for (int s = 0; s < NKS; ++s) {
@@ -119,10 +122,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
                 m = kb + 8 * g + 4 * i + ((lane & 15) >> 2);
             else
                 m = kb + 4 * g + i;
-            if (m > 127) m = 127;
+            if (m > TPX - 1) m = TPX - 1;
             rg[s][i] = m * k.psg;  // rows >= tilepx are zero-filled in sG
             if (m >= tilepx) m = 0;
-            const int ty = m / p.TW, tx = m - ty * p.TW;
+            const int ty = fdiv(m, k.r_TW), tx = m - ty * p.TW;
             rh[s][i] = ((ty * p.stride) * k.HC + tx * p.stride) * k.psh;
         }
     }
@@ -131,9 +134,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
     int g_go[NVG], h_go[NVH];
 
     auto setup = [&](int t) {
-        const int tr = t / k.tiles_c, tc = t - tr * k.tiles_c;
+        const int tr = fdiv(t, k.r_tc), tc = t - tr * k.tiles_c;
         const int vr0 = tr * p.TH, c0 = tc * p.TW;
-        const int gb0 = vr0 / vpitch, gy0 = vr0 - gb0 * vpitch;
+        const int gb0 = fdiv(vr0, k.r_vp), gy0 = vr0 - gb0 * vpitch;
 #pragma unroll
         for (int i = 0; i < NVG; ++i) {
             g_go[i] = -1;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
             }
         }
         const int vrs = vr0 * p.stride, cb = c0 * p.stride - k.pad;
-        const int hb0 = vrs / k.PI, hy0 = vrs - hb0 * k.PI - k.pad;
+        const int hb0 = fdiv(vrs, k.r_PI), hy0 = vrs - hb0 * k.PI - k.pad;
 #pragma unroll
         for (int i = 0; i < NVH; ++i) {
             h_go[i] = -1;
@@ -206,13 +209,37 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
 
     int t = blockIdx.x;
     bool have = t < k.npt;
+    WSTAMP(1);
+    // BatchNorm constants (wave 3: lanes 0-31 those of g, 32-63 those of h): the statistics loads are
+    // issued ahead of the first tile's loads, the arithmetic runs while those are in flight
+    SrcRaw raw;
+    const bool cw = wave == 3, cg = lane < 32;
+    const int cch = lane & 31;
+    const bool cok = cw && (cg ? co0 + cch < p.Co : ci0 + cch < p.Ci);
+    if (cok) {
+        if (cg) src_raw_load(p.g, co0 + cch, p.Co, raw);
+        else src_raw_load(p.h, ci0 + cch, p.Ci, raw);
+    }
     if (have) setup(t);
     issue(have);
+    WSTAMP(2);
+    if (cw) {
+        float a = 0.f, b = 0.f, cc = 0.f;
+        if (cok) {
+            if (cg) src_raw_finish(p.g, raw, a, b, cc);
+            else src_raw_finish(p.h, raw, a, b, cc);
+        }
+        if (cg) cgc[cch] = a, cgc[32 + cch] = b, cgc[64 + cch] = cc;
+        else chc[cch] = a, chc[32 + cch] = b;
+    }
     __syncthreads();  // constants visible
+    WSTAMP(3);
+    bool first = true;
 
     while (have) {
         write_lds();
         __syncthreads();
+        if (first) WSTAMP(4);
         const int tn = t + gridDim.x;
         const bool have_n = tn < k.npt;
         if (have_n) setup(tn);
@@ -236,45 +263,69 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
             }
         }
         __syncthreads();
+        if (first) WSTAMP(5);
+        first = false;
         t = tn, have = have_n;
     }
-    // ---- reduce the 4 waves through LDS, write this block's slab
-    float* red = reinterpret_cast<float*>(smem + k.off_g);  // [4*TAPS][256]
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
+    WSTAMP(6);
+    // ---- reduce the 4 waves through two LDS regions (fixed order (w0+w2)+(w1+w3): deterministic),
+    // then every wave writes one (mt, nt) quadrant of the block's slab.
+    // region layout: [tile = (mt*2+nt)*TAPS+tap][lane] f32x4 -> conflict-free 16-byte accesses
+    f32x4* red = reinterpret_cast<f32x4*>(smem + k.off_g);
+    constexpr int RT = 4 * TAPS * 64;  // f32x4 per region
+    {
+        f32x4* mine = red + (wave & 1) * RT + lane;
+        if (wave >= 2) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int tap = 0; tap < TAPS; ++tap)
+                    for (int tap = 0; tap < TAPS; ++tap) mine[((mt * 2 + nt) * TAPS + tap) * 64] = acc[mt][nt][tap];
+        }
+        __syncthreads();
+        if (wave < 2) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float* d = red + (((mt * 2 + nt) * TAPS + tap) * 256 + lane * 4 + r);
-                            *d = (w == 0 ? 0.f : *d) + acc[mt][nt][tap][r];
-                        }
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int tap = 0; tap < TAPS; ++tap) {
+                        f32x4* d = mine + ((mt * 2 + nt) * TAPS + tap) * 64;
+                        *d = acc[mt][nt][tap] + *d;
+                    }
         }
         __syncthreads();
     }
-    float* slab = p.partial + (size_t)blockIdx.x * p.Co * TAPS * p.Ci;
-    for (int e = tid; e < 32 * TAPS * 32; e += 256) {
-        const int col = e / (TAPS * 32), rem = e - col * (TAPS * 32), tap = rem >> 5, cil = rem & 31;
-        if (co0 + col >= p.Co || ci0 + cil >= p.Ci) continue;
-        const int mt = col >> 4, nt = cil >> 4;
-        const int ln = (cil & 15) + 16 * ((col & 15) >> 2), r = col & 3;
-        slab[((size_t)(co0 + col) * TAPS + tap) * p.Ci + ci0 + cil] = red[((mt * 2 + nt) * TAPS + tap) * 256 + ln * 4 + r];
+    WSTAMP(7);
+    {
+        float* slab = p.partial + (size_t)blockIdx.x * p.Co * TAPS * p.Ci;
+        const int mt = wave >> 1, nt = wave & 1;
+        const int ci = ci0 + nt * 16 + (lane & 15), co = co0 + mt * 16 + 4 * g;
+        const f32x4* src = red + (wave * TAPS) * 64 + lane;
+        float* dst = slab + (size_t)co * TAPS * p.Ci + ci;
+        const bool ciok = ci < p.Ci;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const f32x4 v = src[tap * 64] + src[RT + tap * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ciok && co + r < p.Co) dst[((size_t)r * TAPS + tap) * p.Ci] = v[r];
+        }
     }
+    WSTAMP(8);
 }
 
-template <typename T, int KS, int NVH, bool GQ>
+template <typename T, int KS, int NVH, bool GQ, int TPX = 128>
 int launch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
+    constexpr int OCC = (NVH == 3 && TPX == 128 && sizeof(T) == 2) ? 2 : 1;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, KS, NVH, GQ>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, KS, NVH, GQ, TPX, OCC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((wgrad_kernel<T, KS, NVH, GQ>), grid, dim3(256), lds, st, k);
+    hipLaunchKernelGGL((wgrad_kernel<T, KS, NVH, GQ, TPX, OCC>), grid, dim3(256), lds, st, k);
     STL_LAUNCH_CHECK("conv_wgrad");
     return 0;
 }
@@ -284,6 +335,12 @@ int dispatch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
     const int vpx = 32 / ET<T>::KV;
     const int nvh = ceil_div(k.HP * vpx, 256);
     const bool gq = k.p.g.mode == STL_SRC_BNBWD;
+    if (k.p.TH * k.p.TW > 128) {  // 256-pixel tiles: bf16, halo of at most 6 vectors per thread
+        if constexpr (sizeof(T) == 2) {
+            if (nvh <= 6) return gq ? launch<T, KS, 6, true, 256>(k, grid, lds, st) : launch<T, KS, 6, false, 256>(k, grid, lds, st);
+        }
+        return stl_set_error("wgrad: 256-pixel tiles need bf16 and a halo of at most 384 pixels (have %d)", k.HP);
+    }
     if (nvh <= 3) return gq ? launch<T, KS, 3, true>(k, grid, lds, st) : launch<T, KS, 3, false>(k, grid, lds, st);
     if (nvh <= 6) return gq ? launch<T, KS, 6, true>(k, grid, lds, st) : launch<T, KS, 6, false>(k, grid, lds, st);
     if (nvh <= 9) return gq ? launch<T, KS, 9, true>(k, grid, lds, st) : launch<T, KS, 9, false>(k, grid, lds, st);
@@ -293,6 +350,10 @@ int dispatch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int stl_debug_wgrad_stamps(long long* host16) {
+    return hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_wstamps), 16 * sizeof(long long)) == hipSuccess ? 0 : stl_set_error("stamps: copy failed");
+}
+
 extern "C" int stl_conv_wgrad(const stl_wgrad* pp, void* stream) {
     const stl_wgrad& p = *pp;
     STL_CHECK(p.dtype == STL_F32 || p.dtype == STL_BF16, "wgrad: bad dtype");
@@ -300,7 +361,7 @@ extern "C" int stl_conv_wgrad(const stl_wgrad* pp, void* stream) {
     STL_CHECK(p.stride == 1 || p.stride == 2, "wgrad: stride must be 1 or 2");
     const int kv = p.dtype == STL_BF16 ? 8 : 4;
     STL_CHECK(p.Ci % kv == 0 && p.Co % kv == 0, "wgrad: Ci=%d / Co=%d must be multiples of %d", p.Ci, p.Co, kv);
-    STL_CHECK(p.TH >= 1 && p.TW >= 1 && p.TH * p.TW <= 128, "wgrad: tile exceeds 128 pixels");
+    STL_CHECK(p.TH >= 1 && p.TW >= 1 && p.TH * p.TW <= 256, "wgrad: tile exceeds 256 pixels");
     STL_CHECK((int64_t)p.B * p.Hi * p.Wi * p.Ci < (1ll << 31) && (int64_t)p.B * p.Ho * p.Wo * p.Co < (1ll << 31),
               "wgrad: tensors of 2^31 or more elements are not supported");
     const int pad = p.ks == 3 ? 1 : 0;
@@ -313,6 +374,7 @@ extern "C" int stl_conv_wgrad(const stl_wgrad* pp, void* stream) {
     STL_CHECK(p.h.mode != STL_SRC_BN || (p.h.gamma && p.h.beta && (p.h.stats || (p.h.rmean && p.h.rvar))), "wgrad: BN source incomplete");
     WgK k;
     k.p = p;
+    k.dbg = getenv("STL_CONV_STAMPS") ? 1 : 0;
     k.taps = p.ks * p.ks;
     k.pad = pad;
     k.PI = p.stride * (p.Ho + 1);
@@ -321,13 +383,15 @@ extern "C" int stl_conv_wgrad(const stl_wgrad* pp, void* stream) {
     k.HP = k.HR * k.HC;
     k.tiles_c = ceil_div(p.Wo, p.TW);
     k.npt = ceil_div(p.B * (p.Ho + 1), p.TH) * k.tiles_c;
+    k.r_TW = 1.0f / p.TW, k.r_HC = 1.0f / k.HC, k.r_tc = 1.0f / k.tiles_c, k.r_vp = 1.0f / (p.Ho + 1), k.r_PI = 1.0f / k.PI;
+    STL_CHECK((int64_t)k.npt < (1 << 21) && (int64_t)p.B * k.PI < (1 << 21), "wgrad: too many tiles");
     const int esz = p.dtype == STL_BF16 ? 2 : 4;
     k.psg = k.psh = 32 * esz + 16;
     k.off_cg = 0;
     k.off_ch = 3 * 32 * 4;
     k.off_g = 1024;  // consts: g [3][32] floats at 0, h [2][32] floats at 384 -> 640 B used
-    int szG = 128 * k.psg;
-    const int szRed = 4 * k.taps * 256 * 4;
+    int szG = (p.TH * p.TW > 128 ? 256 : 128) * k.psg;
+    const int szRed = 2 * 4 * k.taps * 64 * 16;  // two regions of [4*taps][64] f32x4
     int szH = k.HP * k.psh;
     k.off_h = k.off_g + szG;
     size_t lds = (size_t)k.off_h + szH;

@@ -35,20 +35,21 @@ def _esz(dtype: int) -> int:
     return 2 if dtype == capi.BF16 else 4
 
 
-def choose_tile(B: int, Ho: int, Wo: int, stride: int, ks: int, esz: int, bn_cols: int = 64) -> Tuple[int, int]:
+def choose_tile(B: int, Ho: int, Wo: int, stride: int, ks: int, esz: int, bn_cols: int = 64,
+                maxpx: int = 128, maxhalo: int = 576) -> Tuple[int, int]:
     """Pick the output tile (TH virtual rows x TW columns, TH*TW <= 128) that wastes the fewest
     MFMA rows / halo loads while fitting LDS."""
     vrows = B * (Ho + 1)
-    best, best_tile = -1.0, (1, min(Wo, 128))
-    for tw in range(min(Wo, 4), min(Wo, 128) + 1):
-        th = max(1, min(128 // tw, vrows))
+    best, best_tile = -1.0, (1, min(Wo, maxpx))
+    for tw in range(min(Wo, 4), min(Wo, maxpx) + 1):
+        th = max(1, min(maxpx // tw, vrows))
         hr, hc = (th - 1) * stride + ks, (tw - 1) * stride + ks
         lds = hr * hc * 80 + bn_cols * (ks * ks * 64 + 16) + 8192
-        if lds > 150 * 1024 or hr * hc > 576:   # 576 halo pixels = 9 staging vectors per thread
+        if lds > 150 * 1024 or hr * hc > maxhalo:   # 576 halo pixels = 9 staging vectors per thread
             continue
         cols = math.ceil(Wo / tw) * tw
         rows = math.ceil(vrows / th) * th
-        eff = (Wo / cols) * (B * Ho / rows) * (th * tw / 128.0)
+        eff = (Wo / cols) * (B * Ho / rows) * (th * tw / float(maxpx))
         eff *= ((th * tw) / float(hr * hc) * stride * stride) ** 0.25  # mild halo penalty
         if eff > best:
             best, best_tile = eff, (th, tw)
@@ -383,11 +384,21 @@ class Engine:
                 wg.dtype = self.dtype
                 wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = x.B, x.H, x.W, x.C, y.H, y.W, y.C
                 wg.ks, wg.stride = kks, kstride
-                wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32)
+                big = (self.esz == 2 and kstride == 1 and os.environ.get("STLPOSE_WGRAD_TILE", "256") == "256"
+                       and x.B * y.H * y.W >= 256 * 64)
+                if big:   # 256-pixel tiles: fewer barriers per pixel, but one block per CU
+                    wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32, maxpx=256, maxhalo=384)
+                else:
+                    wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32)
                 npt = math.ceil(x.B * (y.H + 1) / wg.TH) * math.ceil(y.W / wg.TW)
                 chunks = math.ceil(y.C / 32) * math.ceil(x.C / 32)
-                budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS", "256"))
-                wg.nsplit = max(1, min(npt, budget // chunks if chunks <= budget else 1))
+                # split-K factor: one block per CU, or two where the kernel variant is compiled for two
+                # resident blocks (bf16, 128-pixel tile, halo of at most 3 staging vectors per thread)
+                halo = ((wg.TH - 1) * kstride + kks) * ((wg.TW - 1) * kstride + kks)
+                occ2 = self.esz == 2 and not big and halo * 4 <= 3 * 256
+                budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS", "0")) or (512 if occ2 else 256)
+                top = max(1, min(npt, budget // chunks if chunks <= budget else 1))
+                wg.nsplit = min(range(1, top + 1), key=lambda ns: (math.ceil(npt / ns) + 0.004 * ns * chunks / 8, ns))
                 wg.h = self._src(x)
                 wg.g = g
                 nel = y.C * kks * kks * x.C

@@ -103,15 +103,18 @@ def test_conv_forward_plain_and_stats(case, dt, tile):
     assert torch.allclose(sums[1], (stored * stored).sum(0), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("wtile", [128, 256])
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(2, 24, 16, 32, 32, 3, 1), (2, 24, 18, 32, 64, 3, 2), (2, 8, 6, 128, 64, 1, 1),
                                   (4, 48, 36, 64, 64, 3, 1), (4, 24, 18, 128, 128, 3, 1)])
-def test_conv_bn_relu_chain_forward_backward(case, dt):
+def test_conv_bn_relu_chain_forward_backward(case, dt, wtile):
     """x --BN(relu) on load--> conv --> y ; backward: BN-backward on load, ReLU mask + r1/r2 in the
     data-gradient epilogue, weight gradient slabs.  Reference: torch autograd through
     batch_norm(train) -> relu -> conv2d -> batch_norm(train)."""
     code, td, tol = DT[dt]
     B, H, W, Ci, Co, ks, s = case
+    if wtile == 256 and (dt != "bf16" or s != 1):
+        pytest.skip("256-pixel weight-gradient tiles are bf16, stride 1 only")
     g = torch.Generator(device="cuda").manual_seed(2)
     pad = 1 if ks == 3 else 0
     x0 = torch.randn(B, Ci, H, W, device="cuda", generator=g) * 1.5 + 0.3
@@ -161,7 +164,12 @@ def test_conv_bn_relu_chain_forward_backward(case, dt):
     wg = capi.Wgrad()
     wg.dtype, wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = code, B, H, W, Ci, Ho, Wo, Co
     wg.ks, wg.stride = ks, s
-    wg.TH, wg.TW = choose_tile(B, Ho, Wo, s, ks, x0t.element_size(), bn_cols=32)
+    if wtile == 256:
+        wg.TH, wg.TW = choose_tile(B, Ho, Wo, s, ks, x0t.element_size(), bn_cols=32, maxpx=256, maxhalo=384)
+        if wg.TH * wg.TW <= 128:
+            pytest.skip("feature map smaller than one 256-pixel tile")
+    else:
+        wg.TH, wg.TW = choose_tile(B, Ho, Wo, s, ks, x0t.element_size(), bn_cols=32)
     npt = math.ceil(B * (Ho + 1) / wg.TH) * math.ceil(Wo / wg.TW)
     wg.nsplit = min(3, npt)
     part = torch.full((wg.nsplit * Co * ks * ks * Ci,), float("nan"), device="cuda")

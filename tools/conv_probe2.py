@@ -2,7 +2,7 @@ import os, sys, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 shapes = ["32,96,72,32,32,3,1", "32,48,36,64,64,3,1", "32,24,18,128,128,3,1", "32,12,9,256,256,3,1", "32,96,72,64,256,1,1", "32,96,72,256,64,1,1", "32,96,72,32,64,3,2"]
 for s in shapes:
-    for f in ("auto", "5", "6", "7", "1", "2"):
+    for f in ("auto", "4", "0", "2"):
         env = dict(os.environ)
         if f != "auto":
             env["STL_CONV_SHAPE"] = f

@@ -1,0 +1,10 @@
+import os, sys, subprocess
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+shapes = ["32,96,72,32,32,3,1", "32,48,36,64,64,3,1", "32,24,18,128,128,3,1"]
+for s in shapes:
+    for f in ("4", "0"):
+        for cap in ("256", "512", "768", "1024", "1536", "2048"):
+            env = dict(os.environ, STL_CONV_SHAPE=f, STL_CONV_GRID_CAP=cap, STL_CONV_WS="0")
+            r = subprocess.run([sys.executable, "tools/conv_one.py", s, "30"], env=env, capture_output=True, text=True)
+            line = [l for l in r.stdout.splitlines() if l.startswith("B")]
+            print(f"shape={f} cap={cap:5s}", line[0][:95] if line else r.stderr[-200:], flush=True)

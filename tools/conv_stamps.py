@@ -5,10 +5,11 @@ import ctypes as C, torch
 from stlpose_amd import capi
 from tools.conv_probe import run
 names = ["consts", "descr", "wres-setup", "tile0 setup+issue+sync", "write_lds+sync", "next setup+issue", "mfma+sync", "(gap)", "epilogue", "loop exit", "stats flush"]
-for shape in [(32, 96, 72, 32, 32, 3, 1), (1, 96, 72, 32, 32, 3, 1), (32, 48, 36, 64, 64, 3, 1), (32, 24, 18, 128, 128, 3, 1)]:
-    run(*shape, reps=2)
+for shape in [(32, 96, 72, 32, 32, 3, 1), (32, 48, 36, 64, 64, 3, 1)]:
+    run(*shape, reps=int(os.environ.get('REPS','2')))
     torch.cuda.synchronize()
-    buf = (C.c_longlong * 12)()
+    buf = (C.c_longlong * 14)()
     capi.call("stl_debug_conv_stamps", C.cast(buf, C.c_void_p))
     t = list(buf)
+    print(f"   shader clock = {(t[13]-t[12])/((t[11]-t[0])/100)/1e3:.2f} GHz over {(t[11]-t[0])/100:.1f} us")
     print("   phases (us):", ", ".join(f"{n}={(t[i+1]-t[i])/100:.2f}" for i, n in enumerate(names)), f" total={(t[11]-t[0])/100:.2f}")
