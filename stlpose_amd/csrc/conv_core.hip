@@ -41,6 +41,7 @@ struct ConvK {
     int sz_a, sz_b;  // wave-specialised kernel: byte distance between the two LDS buffers (0 = single)
     int TH, TW;
     int dbg;
+    float r_HC, r_TW, r_tc, r_PI, r_vp;  // reciprocals for fdiv
 };
 
 template <typename T>
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     for (int i = 0; i < NVA; ++i) {
         const int v = tid + i * NTHR;
         if (v < k.HP * 4) {
-            const int hp = v >> 2, hr = hp / k.HC;
+            const int hp = v >> 2, hr = fdiv(hp, k.r_HC);
             a_rc[i] = (hr << 16) | (hp - hr * k.HC);
         } else {
             a_rc[i] = -1;
@@ -141,12 +142,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
         int m = (wm * MT + mi) * 16 + r16;
         e_yx[mi] = -1;
         if (m < tilepx) {
-            const int ty = m / k.TW;
+            const int ty = fdiv(m, k.r_TW);
             e_yx[mi] = (ty << 16) | (m - ty * k.TW);
         } else {
             m = 0;
         }
-        const int ty = m / k.TW, tx = m - ty * k.TW;
+        const int ty = fdiv(m, k.r_TW), tx = m - ty * k.TW;
         xoff[mi] = ((ty * k.seff) * k.HC + tx * k.seff) * PSA + g * 16;
     }
     const int woff = (wn * NTW * 16 + r16) * ROWB + g * 16;
@@ -156,9 +157,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     int a_go[NVA];
 
     auto tile_setup = [&](int t, int* go) {
-        const int tr = t / k.tiles_c, tc = t - tr * k.tiles_c;
+        const int tr = fdiv(t, k.r_tc), tc = t - tr * k.tiles_c;
         const int vrs = tr * k.TH * k.seff, cb = tc * k.TW * k.seff - k.pad;
-        const int b0 = vrs / k.PI, y0 = vrs - b0 * k.PI - k.pad;
+        const int b0 = fdiv(vrs, k.r_PI), y0 = vrs - b0 * k.PI - k.pad;
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
             go[i] = -1;
@@ -225,14 +226,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
         }
     };
 
-    if (k.wres) {  // whole K fits one chunk: filters stay resident in LDS for all tiles
+    if (k.wres) {  // whole K fits one chunk: filters stay resident in LDS for all tiles (rb[] is free then)
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
-            if (tid + i * NTHR < BCO * TAPS * 4) {
-                V16 val = zero16();
-                if (b_g[i] >= 0 && (((tid + i * NTHR) & 3) * KV) < p.Ci) val = ldg16((const char*)p.w + (size_t)b_g[i] * sizeof(T));
-                *reinterpret_cast<V16*>(sB + b_l[i]) = val;
-            }
+            const bool ok = b_g[i] >= 0 && (((tid + i * NTHR) & 3) * KV) < p.Ci;
+            rb[i] = ldg16((const char*)p.w + (size_t)(ok ? b_g[i] : 0) * sizeof(T));
         }
     }
 
@@ -254,6 +252,15 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     STAMP(3);
     if (have) tile_setup(t, a_go);
     issue(a_go, 0, have);
+    if (k.wres) {
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const bool ok = b_g[i] >= 0 && (((tid + i * NTHR) & 3) * KV) < p.Ci;
+            V16 val = rb[i];
+            mask16(val, ok);
+            if (tid + i * NTHR < BCO * TAPS * 4) *reinterpret_cast<V16*>(sB + b_l[i]) = val;
+        }
+    }
     __syncthreads();  // constants + resident filters visible
     STAMP(4);
 
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     // flat loop over stages (tile, chunk); exactly ONE issue() site inside the loop so that the
     // staging registers need no PHI copies (which would force a vmcnt(0) before the MFMAs)
     while (have) {
-        const int tr = t / k.tiles_c, tc = t - tr * k.tiles_c;
+        const int tr = fdiv(t, k.r_tc), tc = t - tr * k.tiles_c;
         const int vr0 = tr * k.TH, c0 = tc * k.TW;
         write_lds(a_go, ch0 * CK);
         __syncthreads();
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
         if (last_chunk) {
             STAMP(8);
             // ---- epilogue straight from the accumulators: lane = pixel r16, 4 channels per tile
-            const int eb0 = vr0 / vpitch, ey0 = vr0 - eb0 * vpitch;
+            const int eb0 = fdiv(vr0, k.r_vp), ey0 = vr0 - eb0 * vpitch;
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
                 bool pok = e_yx[mi] >= 0;
@@ -599,6 +606,8 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     const int vrows = p.B * (p.Ho + 1);
     k.tiles_c = ceil_div(p.Wo, plan.TW);
     k.npt = ceil_div(vrows, plan.TH) * k.tiles_c;
+    k.r_HC = 1.0f / k.HC, k.r_TW = 1.0f / k.TW, k.r_tc = 1.0f / k.tiles_c, k.r_PI = 1.0f / k.PI, k.r_vp = 1.0f / (p.Ho + 1);
+    STL_CHECK(k.npt < (1 << 21) && (int64_t)vrows * 2 < (1 << 21) && k.HP < 4096, "conv: index range exceeds the fast-division limits");
     const Shape sh = SHAPES[plan.shape];
     int gx = ceil_div(k.npt, 8) * 8;
     int cap = sh.ws ? 256 : (sh.thr == 512 ? 512 : 1024);

@@ -31,8 +31,6 @@ struct WgK {
     float r_TW, r_HC, r_tc, r_vp, r_PI;  // reciprocals for fdiv
 };
 
-// floor(m / d) for 0 <= m < 2^21 with r = 1/d (d <= 2^10): exact, ~4 instructions instead of ~40
-__device__ __forceinline__ int fdiv(int m, float r) { return (int)(((float)m + 0.5f) * r); }
 
 template <typename T>
 __device__ __forceinline__ V16 frag_tr(const char* base, const int* rowoff, int colbyte, int lane);
