@@ -476,8 +476,9 @@ Plan choose_plan(const stl_conv& p, int ck) {
         if (c32 && shape != 4) continue;
         // kernel family: measured on MI355X (tools/conv_probe2.py) the wave-specialised kernel wins for
         // stride-2 convs and for the small, deep maps (Co >= 256), the uniform kernel elsewhere
+        const int ws_minco = getenv("STL_CONV_WS_MINCO") ? atoi(getenv("STL_CONV_WS_MINCO")) : 256;
         const int want_ws = getenv("STL_CONV_WS") ? atoi(getenv("STL_CONV_WS"))
-                                                  : ((p.stride == 2 || (p.ks == 3 && p.Co >= 256 && (int64_t)p.B * p.Ho * p.Wo <= 8192)) ? 1 : 0);
+                                                  : ((p.stride == 2 || (p.ks == 3 && p.Co >= ws_minco && (int64_t)p.B * p.Ho * p.Wo <= 16384)) ? 1 : 0);
         if (sh.ws != want_ws) continue;
         if (want_ws && !getenv("STL_CONV_WS") && shape != 7) continue;
         const int nblk_co = ceil_div(p.Co, sh.co);

@@ -157,7 +157,11 @@ class Engine:
         self.stats = torch.zeros(max(nstat, 1), dtype=torch.float64, device=self.dev)
         self.rstats = torch.zeros(max(nstat, 1), dtype=torch.float64, device=self.dev) if training else None
         self.nstreams = int(os.environ.get("STLPOSE_STREAMS", "4"))
-        self.wgrad_streams = os.environ.get("STLPOSE_WGRAD_STREAMS", "1") != "0"
+        # weight-gradient streams: "0" = none (same stream as the branch), "1" = one per branch stream,
+        # "n<k>" = k shared streams (branch s -> weight-gradient stream s % k)
+        wgs = os.environ.get("STLPOSE_WGRAD_STREAMS", "1")
+        self.wgrad_streams = wgs != "0"
+        self.nwstreams = 0 if wgs == "0" else (int(wgs[1:]) if wgs.startswith("n") else self.nstreams)
         self._stream = 0
         self._side = None
         self._stats_used = 0
@@ -408,7 +412,7 @@ class Engine:
                                        ks=ci.ks, Cip=ci.Cik, patch=int(ci.patch), stride=0, struct=wg))
                 # weight gradients are off the critical path (only the data-gradient chain is): give
                 # them their own streams so they overlap with the chain
-                wstrm = (strm + self.nstreams) if self.wgrad_streams else strm
+                wstrm = (self.nstreams + strm % self.nwstreams) if self.wgrad_streams else strm
                 ops.append(("stl_conv_wgrad", wg, wstrm, [y.dt.data_ptr(), x.ptr], [id(wg)]))
                 # ---- data gradient
                 if not x.needs_grad:
@@ -505,7 +509,7 @@ class Engine:
 
     @property
     def total_streams(self) -> int:
-        return self.nstreams * (2 if self.wgrad_streams else 1)
+        return self.nstreams + self.nwstreams
 
     def _run(self, ops, stream: int):
         """Replay a program natively.  With several streams the independent branches of each
