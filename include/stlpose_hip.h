@@ -176,7 +176,7 @@ int stl_weight_prep(int dtype, const float* master, void* wk, const stl_wprep* t
                     int nblocks, void* stream);
 
 typedef struct stl_slab { /* one wgrad result: sum partial[s] -> grad (OIHW fp32) */
-    int64_t part_off; /* element offset into `partials` */
+    int64_t part_off; /* element offset into `partials`; a multiple of 4 (16-byte aligned) when Ci % 4 == 0 */
     int64_t grad_off; /* element offset into `grads`    */
     int32_t nsplit, Co, Ci, ks, Cip, patch, blk0;
     int32_t pad; /* if non-zero: element stride between consecutive splits (default Co*taps*Ci) */

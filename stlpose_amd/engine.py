@@ -333,7 +333,7 @@ class Engine:
                 dx = self._new_grad(x)
                 nel = joints * x.C + joints
                 part_off = self._slab_elems
-                self._slab_elems += nblk * nel
+                self._slab_elems += (nblk * nel + 3) // 4 * 4   # keep every entry 16-byte aligned
                 hb = capi.HeadBwd()
                 hb.dtype, hb.B, hb.H, hb.W, hb.Ci, hb.J, hb.nblk = self.dtype, x.B, x.H, x.W, x.C, joints, nblk
                 hb.x, hb.w, hb.dout, hb.dx = x.ptr, self.head_w, self.dout.data_ptr(), dx.data_ptr()
@@ -407,7 +407,7 @@ class Engine:
                 wg.g = g
                 nel = y.C * kks * kks * x.C
                 part_off = self._slab_elems
-                self._slab_elems += wg.nsplit * nel
+                self._slab_elems += (wg.nsplit * nel + 3) // 4 * 4
                 self.slabs.append(dict(part_off=part_off, grad_off=ci.master_off, nsplit=wg.nsplit, Co=ci.Co, Ci=ci.Ci,
                                        ks=ci.ks, Cip=ci.Cik, patch=int(ci.patch), stride=0, struct=wg))
                 # weight gradients are off the critical path (only the data-gradient chain is): give
