@@ -166,10 +166,23 @@ def main():
         dom = time_dominant_kernel(ts)
         roof = None
         if dom:
+            # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+            # (tools/pmc_traffic.py -> profiles/r*_pmc_wgrad.json); null if they describe another config
+            traffic = None
+            import glob
+            for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_wgrad.json"))):
+                try:
+                    rec = json.load(open(f))
+                    if rec.get("launches") == dom["launches"] and (a.arch, a.height, a.width, a.batch, a.dtype) == ("w32", 384, 288, 32, "bf16"):
+                        traffic = round(rec["traffic_bytes_per_launch"])
+                except Exception:
+                    pass
             roof = dict(bound="mfma", achieved=round(dom["tflops"], 2), peak=MFMA_PEAK_BF16, unit="TFLOP/s",
-                        frac=round(dom["tflops"] / MFMA_PEAK_BF16, 4), traffic=None, kernel=dom["kernel"],
+                        frac=round(dom["tflops"] / MFMA_PEAK_BF16, 4), traffic=traffic, kernel=dom["kernel"],
                         launches_per_step=dom["launches"], avg_launch_us=round(dom["ms"] * 1e3, 2),
-                        algorithmic_GBps=round(dom["gbs"], 1), hbm_frac=round(dom["gbs"] / HBM_PEAK, 4))
+                        algorithmic_GBps=round(dom["gbs"], 1), hbm_frac=round(dom["gbs"] / HBM_PEAK, 4),
+                        algorithmic_bytes_per_launch=round(dom["gbs"] * dom["ms"] * 1e6),
+                        traffic_unit="HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)")
         out = dict(metric="images/sec/GPU HRNet-W32 384x288 train step; PCKh@0.5 parity", value=round(value, 2),
                    unit="images/sec", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.dtype, data="synthetic",

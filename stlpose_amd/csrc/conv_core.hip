@@ -611,7 +611,10 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     STL_CHECK(k.npt < (1 << 21) && (int64_t)vrows * 2 < (1 << 21) && k.HP < 4096, "conv: index range exceeds the fast-division limits");
     const Shape sh = SHAPES[plan.shape];
     int gx = ceil_div(k.npt, 8) * 8;
-    int cap = sh.ws ? 256 : (sh.thr == 512 ? 512 : 1024);
+    // resident waves per SIMD ~2: persistent blocks that loop over their tiles with the next tile's
+    // loads in flight beat a second round of fresh blocks (measured: tools/conv_probe7.py)
+    int cap = sh.ws ? 256 : (sh.thr == 512 ? 256 : 1024);
+    if (const char* e = getenv("STL_CONV_CAP512")) cap = sh.ws ? 256 : (sh.thr == 512 ? atoi(e) : 1024);
     if (const char* e = getenv("STL_CONV_GRID_CAP")) cap = atoi(e) > 0 ? (atoi(e) + 7) / 8 * 8 : cap;
     if (gx > cap) gx = cap;
     dim3 grid(gx, ceil_div(p.Co, sh.co));

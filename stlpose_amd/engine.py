@@ -401,6 +401,10 @@ class Engine:
                 halo = ((wg.TH - 1) * kstride + kks) * ((wg.TW - 1) * kstride + kks)
                 occ2 = self.esz == 2 and not big and halo * 4 <= 3 * 256
                 budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS", "0")) or (512 if occ2 else 256)
+                if kks == 1 and self.esz == 2:
+                    # 1x1: a single accumulator tile per wave -> three blocks fit a CU, and the K loop is
+                    # pure per-tile latency, so spread the pixels over three times as many blocks
+                    budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS_K1", "512"))
                 top = max(1, min(npt, budget // chunks if chunks <= budget else 1))
                 wg.nsplit = min(range(1, top + 1), key=lambda ns: (math.ceil(npt / ns) + 0.004 * ns * chunks / 8, ns))
                 wg.h = self._src(x)
