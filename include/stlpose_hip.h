@@ -92,6 +92,9 @@ typedef struct stl_wgrad {
     float* partial; /* [nsplit][Co][ks*ks][Ci] */
 } stl_wgrad;
 int stl_conv_wgrad(const stl_wgrad* p, void* stream);
+/* Channel tile (32 or 64) of the kernel variant stl_conv_wgrad uses for this problem: the grid is
+ * nsplit x ceil(Co/tile) x ceil(Ci/tile) blocks, which is what a caller sizes nsplit against. */
+int stl_wgrad_chunk(const stl_wgrad* p);
 
 /* Sum of up to 4 terms + optional ReLU, each term read through an stl_src and optionally
  * nearest-upsampled by 2^shift.  Replaces the residual add+ReLU of the reference's blocks

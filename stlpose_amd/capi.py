@@ -98,6 +98,7 @@ SIGNATURES = {
     "stl_debug_conv_stamps2": [vp],
     "stl_debug_wgrad_stamps": [vp],
     "stl_conv_wgrad": [C.POINTER(Wgrad), vp],
+    "stl_wgrad_chunk": [C.POINTER(Wgrad)],
     "stl_fuse_forward": [C.POINTER(Fuse), vp],
     "stl_fuse_backward": [C.POINTER(FuseBwd), vp],
     "stl_upsample_backward": [C.POINTER(UpBwd), vp],

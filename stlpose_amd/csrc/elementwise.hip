@@ -473,33 +473,6 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* master, T
     const int t = e.ks * e.ks;
     const int64_t tot = (int64_t)e.Co * e.Ci * t;
     const int64_t base = (int64_t)(blockIdx.x - e.blk0) * 1024;
-    if (!e.patch && (e.Ci & 3) == 0) {
-        // fast path: walk the slabs in THEIR order ([Co][taps][Ci], 16-byte coalesced reads, four slabs
-        // in flight), scatter the four sums into the OIHW gradient (1/nsplit of the traffic)
-        const int64_t j = base + 4 * threadIdx.x;
-        if (j >= tot) return;
-        const float* src = partials + e.part_off + j;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        int k = 0;
-        for (; k + 4 <= e.nsplit; k += 4) {
-            const float4 a0 = *reinterpret_cast<const float4*>(src + (int64_t)(k + 0) * slab);
-            const float4 a1 = *reinterpret_cast<const float4*>(src + (int64_t)(k + 1) * slab);
-            const float4 a2 = *reinterpret_cast<const float4*>(src + (int64_t)(k + 2) * slab);
-            const float4 a3 = *reinterpret_cast<const float4*>(src + (int64_t)(k + 3) * slab);
-            s.x += a0.x, s.y += a0.y, s.z += a0.z, s.w += a0.w;
-            s.x += a1.x, s.y += a1.y, s.z += a1.z, s.w += a1.w;
-            s.x += a2.x, s.y += a2.y, s.z += a2.z, s.w += a2.w;
-            s.x += a3.x, s.y += a3.y, s.z += a3.z, s.w += a3.w;
-        }
-        for (; k < e.nsplit; ++k) {
-            const float4 a0 = *reinterpret_cast<const float4*>(src + (int64_t)k * slab);
-            s.x += a0.x, s.y += a0.y, s.z += a0.z, s.w += a0.w;
-        }
-        const int co = (int)(j / (t * e.Ci)), rem = (int)(j - (int64_t)co * t * e.Ci), tap = rem / e.Ci, ci = rem - tap * e.Ci;
-        float* d = grads + e.grad_off + ((int64_t)co * e.Ci + ci) * t + tap;
-        d[0] = s.x, d[t] = s.y, d[2 * t] = s.z, d[3 * t] = s.w;
-        return;
-    }
     for (int r = 0; r < 4; ++r) {
         const int64_t i = base + r * 256 + threadIdx.x;
         if (i >= tot) return;

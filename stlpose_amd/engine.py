@@ -388,20 +388,26 @@ class Engine:
                 wg.dtype = self.dtype
                 wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = x.B, x.H, x.W, x.C, y.H, y.W, y.C
                 wg.ks, wg.stride = kks, kstride
+                ctile = capi.lib().stl_wgrad_chunk(C.byref(wg))   # 32, or 64 for the wide-channel variant
                 big = (self.esz == 2 and kstride == 1 and os.environ.get("STLPOSE_WGRAD_TILE", "256") == "256"
-                       and x.B * y.H * y.W >= 256 * 64)
+                       and x.B * y.H * y.W >= 256 * 64 and (ctile == 32 or kks == 1))
                 if big:   # 256-pixel tiles: fewer barriers per pixel, but one block per CU
-                    wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32, maxpx=256, maxhalo=384)
+                    wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32, maxpx=256,
+                                               maxhalo=352 if ctile == 64 else 384)
                 else:
-                    wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32)
+                    wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32,
+                                               maxhalo=192 if ctile == 64 else 576)
                 npt = math.ceil(x.B * (y.H + 1) / wg.TH) * math.ceil(y.W / wg.TW)
-                chunks = math.ceil(y.C / 32) * math.ceil(x.C / 32)
+                chunks = math.ceil(y.C / ctile) * math.ceil(x.C / ctile)
                 # split-K factor: one block per CU, or two where the kernel variant is compiled for two
                 # resident blocks (bf16, 128-pixel tile, halo of at most 3 staging vectors per thread)
                 halo = ((wg.TH - 1) * kstride + kks) * ((wg.TW - 1) * kstride + kks)
-                occ2 = self.esz == 2 and not big and halo * 4 <= 3 * 256
+                occ2 = self.esz == 2 and not big and halo * 4 <= 3 * 256 and ctile == 32
                 budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS", "0")) or (512 if occ2 else 256)
-                if kks == 1 and self.esz == 2:
+                if ctile == 64:
+                    # 64x64 blocks write 4x larger slabs: fewer, longer-running blocks keep the slab traffic down
+                    budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS64", "128"))
+                elif kks == 1 and self.esz == 2:
                     # 1x1: a single accumulator tile per wave -> three blocks fit a CU, and the K loop is
                     # pure per-tile latency, so spread the pixels over three times as many blocks
                     budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS_K1", "512"))

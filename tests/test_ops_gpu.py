@@ -103,16 +103,23 @@ def test_conv_forward_plain_and_stats(case, dt, tile):
     assert torch.allclose(sums[1], (stored * stored).sum(0), rtol=1e-5, atol=1e-3)
 
 
-@pytest.mark.parametrize("wtile", [128, 256])
+@pytest.mark.parametrize("wtile", [128, 256, "wide128", "wide256"])
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(2, 24, 16, 32, 32, 3, 1), (2, 24, 18, 32, 64, 3, 2), (2, 8, 6, 128, 64, 1, 1),
-                                  (4, 48, 36, 64, 64, 3, 1), (4, 24, 18, 128, 128, 3, 1)])
-def test_conv_bn_relu_chain_forward_backward(case, dt, wtile):
+                                  (4, 48, 36, 64, 64, 3, 1), (4, 24, 18, 128, 128, 3, 1), (2, 24, 18, 64, 256, 1, 1),
+                                  (2, 24, 18, 96, 72, 3, 1)])
+def test_conv_bn_relu_chain_forward_backward(case, dt, wtile, monkeypatch):
     """x --BN(relu) on load--> conv --> y ; backward: BN-backward on load, ReLU mask + r1/r2 in the
     data-gradient epilogue, weight gradient slabs.  Reference: torch autograd through
     batch_norm(train) -> relu -> conv2d -> batch_norm(train)."""
     code, td, tol = DT[dt]
     B, H, W, Ci, Co, ks, s = case
+    wide = isinstance(wtile, str)   # opt-in 64x64-channel weight-gradient variant
+    if wide:
+        wtile = int(wtile[4:])
+        if dt != "bf16" or s != 1 or Ci < 64 or Co < 64:
+            pytest.skip("the wide variant is bf16, stride 1, Co and Ci >= 64")
+        monkeypatch.setenv("STL_WGRAD_64", "1")
     if wtile == 256 and (dt != "bf16" or s != 1):
         pytest.skip("256-pixel weight-gradient tiles are bf16, stride 1 only")
     g = torch.Generator(device="cuda").manual_seed(2)
@@ -164,12 +171,16 @@ def test_conv_bn_relu_chain_forward_backward(case, dt, wtile):
     wg = capi.Wgrad()
     wg.dtype, wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = code, B, H, W, Ci, Ho, Wo, Co
     wg.ks, wg.stride = ks, s
+    ctile = capi.lib().stl_wgrad_chunk(C.byref(wg))   # 64: wide-channel kernel variant (bf16, Co, Ci >= 64)
+    assert ctile == (64 if wide else 32)
     if wtile == 256:
-        wg.TH, wg.TW = choose_tile(B, Ho, Wo, s, ks, x0t.element_size(), bn_cols=32, maxpx=256, maxhalo=384)
+        if ctile == 64 and ks == 3:
+            pytest.skip("the 64x64 3x3 variant has 128-pixel tiles only")
+        wg.TH, wg.TW = choose_tile(B, Ho, Wo, s, ks, x0t.element_size(), bn_cols=32, maxpx=256, maxhalo=352 if ctile == 64 else 384)
         if wg.TH * wg.TW <= 128:
             pytest.skip("feature map smaller than one 256-pixel tile")
     else:
-        wg.TH, wg.TW = choose_tile(B, Ho, Wo, s, ks, x0t.element_size(), bn_cols=32)
+        wg.TH, wg.TW = choose_tile(B, Ho, Wo, s, ks, x0t.element_size(), bn_cols=32, maxhalo=192 if ctile == 64 else 576)
     npt = math.ceil(B * (Ho + 1) / wg.TH) * math.ceil(Wo / wg.TW)
     wg.nsplit = min(3, npt)
     part = torch.full((wg.nsplit * Co * ks * ks * Ci,), float("nan"), device="cuda")

@@ -5,7 +5,10 @@ import ctypes as C, torch
 from stlpose_amd import capi
 from tools.conv_probe import run
 names = ["consts", "descr", "wres-setup", "tile0 setup+issue+sync", "write_lds+sync", "next setup+issue", "mfma+sync", "(gap)", "epilogue", "loop exit", "stats flush"]
-for shape in [(32, 96, 72, 32, 32, 3, 1), (32, 48, 36, 64, 64, 3, 1)]:
+shapes = [(32, 96, 72, 32, 32, 3, 1), (32, 48, 36, 64, 64, 3, 1)]
+if os.environ.get("SHAPES"):
+    shapes = [tuple(int(v) for v in t.split(",")) for t in os.environ["SHAPES"].split(";")]
+for shape in shapes:
     run(*shape, reps=int(os.environ.get('REPS','2')))
     torch.cuda.synchronize()
     buf = (C.c_longlong * 14)()
