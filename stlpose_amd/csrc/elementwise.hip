@@ -780,9 +780,9 @@ extern "C" int stl_fuse_forward(const stl_fuse* pp, void* stream) {
     const size_t total = (size_t)p.B * p.H * p.W * (p.C / 8);
     const size_t lds = (size_t)p.nterms * 2 * p.C * 4;
     if (p.dtype == STL_BF16)
-        hipLaunchKernelGGL(fuse_fwd_kernel<__bf16>, dim3(nblocks_for(total)), dim3(256), lds, ST, p);
+        hipLaunchKernelGGL(fuse_fwd_kernel<__bf16>, dim3(nblocks_for(total, 256, getenv("STL_FUSEF_BLOCKS") ? atoi(getenv("STL_FUSEF_BLOCKS")) : 2048)), dim3(256), lds, ST, p);
     else
-        hipLaunchKernelGGL(fuse_fwd_kernel<float>, dim3(nblocks_for(total)), dim3(256), lds, ST, p);
+        hipLaunchKernelGGL(fuse_fwd_kernel<float>, dim3(nblocks_for(total, 256, getenv("STL_FUSEF_BLOCKS") ? atoi(getenv("STL_FUSEF_BLOCKS")) : 2048)), dim3(256), lds, ST, p);
     STL_LAUNCH_CHECK("fuse_forward");
     return 0;
 }
@@ -800,7 +800,7 @@ extern "C" int stl_fuse_backward(const stl_fuse_bwd* pp, void* stream) {
     for (int t = 0; t < p.nbn; ++t) STL_CHECK(p.bn[t].x && p.bn[t].stats && p.rstats[t], "fuse_bwd: bn term %d incomplete", t);
     const int bd = stat_block(p.C);
     const size_t total = (size_t)p.B * p.H * p.W * (p.C / 8);
-    int nb = nblocks_for(total, bd, 512);
+    int nb = nblocks_for(total, bd, getenv("STL_FUSE_BLOCKS") ? atoi(getenv("STL_FUSE_BLOCKS")) : 256);
     const size_t lds = (size_t)(p.nbn > 0 ? p.nbn : 1) * 2 * p.C * 4 + (size_t)bd * 2 * 8 * 4;
     if (p.dtype == STL_BF16)
         hipLaunchKernelGGL(fuse_bwd_kernel<__bf16>, dim3(nb), dim3(bd), lds, ST, p);
@@ -817,7 +817,7 @@ extern "C" int stl_upsample_backward(const stl_upbwd* pp, void* stream) {
     STL_CHECK(p.du && p.dt && p.bn.x && p.bn.stats && p.rstats, "upsample_bwd: null pointer");
     const int bd = stat_block(p.C);
     const size_t total = (size_t)p.B * p.H * p.W * (p.C / 8);
-    int nb = nblocks_for(total, bd, 512);
+    int nb = nblocks_for(total, bd, getenv("STL_FUSE_BLOCKS") ? atoi(getenv("STL_FUSE_BLOCKS")) : 256);
     const size_t lds = (size_t)2 * p.C * 4 + (size_t)bd * 2 * 8 * 4;
     if (p.dtype == STL_BF16)
         hipLaunchKernelGGL(upsample_bwd_kernel<__bf16>, dim3(nb), dim3(bd), lds, ST, p);

@@ -399,18 +399,14 @@ class Engine:
                                                maxhalo=192 if ctile == 64 else 576)
                 npt = math.ceil(x.B * (y.H + 1) / wg.TH) * math.ceil(y.W / wg.TW)
                 chunks = math.ceil(y.C / ctile) * math.ceil(x.C / ctile)
-                # split-K factor: one block per CU, or two where the kernel variant is compiled for two
-                # resident blocks (bf16, 128-pixel tile, halo of at most 3 staging vectors per thread)
-                halo = ((wg.TH - 1) * kstride + kks) * ((wg.TW - 1) * kstride + kks)
-                occ2 = self.esz == 2 and not big and halo * 4 <= 3 * 256 and ctile == 32
-                budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS", "0")) or (512 if occ2 else 256)
+                # Block budget per launch: one block per CU.  (End to end, budgets of 128..256 measure the
+                # same within run-to-run noise on MI355X: fewer blocks mean fewer slab bytes but a longer
+                # launch; 256 keeps the launch itself fastest.)
+                budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS", "256"))
                 if ctile == 64:
-                    # 64x64 blocks write 4x larger slabs: fewer, longer-running blocks keep the slab traffic down
                     budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS64", "128"))
                 elif kks == 1 and self.esz == 2:
-                    # 1x1: a single accumulator tile per wave -> three blocks fit a CU, and the K loop is
-                    # pure per-tile latency, so spread the pixels over three times as many blocks
-                    budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS_K1", "512"))
+                    budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS_K1", str(budget)))
                 top = max(1, min(npt, budget // chunks if chunks <= budget else 1))
                 wg.nsplit = min(range(1, top + 1), key=lambda ns: (math.ceil(npt / ns) + 0.004 * ns * chunks / 8, ns))
                 wg.h = self._src(x)
