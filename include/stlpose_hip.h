@@ -71,6 +71,10 @@ typedef struct stl_conv {
     const void* mask_y;    /* [B,Ho,Wo,Co] raw tensor whose BN(+ReLU) gates `out`  */
     stl_src mask_bn;       /* BN parameters for mask_y (mode must be STL_SRC_BN)   */
     double* red;           /* [NSHARD][2*Co] += (r1,r2) against mask_y or NULL     */
+    const void* mask_z;    /* [B,Ho,Wo,Co] dtype or NULL: ReLU output z whose sign gates `out` (out = 0 where
+                              z <= 0).  With addend / mask_y (mask_bn.relu = 0) / red this is the backward of a
+                              residual block end  z = ReLU(BN(y) + x)  fused into the data gradient that
+                              produces the last contribution to dz (HRnet.py:58-59,99-100). */
 } stl_conv;
 int stl_conv_forward(const stl_conv* p, void* stream);
 /* Fill p->shape / p->TH / p->TW once (host-side tile search) so that launches are cheap. */

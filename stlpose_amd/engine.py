@@ -94,6 +94,8 @@ class Act:
     grads: List[torch.Tensor] = field(default_factory=list)  # plain: gradient contributions
     dt: Optional[torch.Tensor] = None                        # bn: grad wrt BN output (masked)
     consumers: int = 0
+    bwd_seen: int = 0                                        # consumers already handled by the backward builder
+    fused_du: Optional[torch.Tensor] = None                  # plain: masked gradient produced by a fused dgrad
 
     @property
     def ptr(self) -> int:
@@ -325,10 +327,13 @@ class Engine:
         self._slab_elems = 0
         J = self.out.shape[1]
         self.dout = torch.zeros_like(self.out)
+        producer = {id(n[2]): n for n in self.tape if n[0] == "fuse"}
+        fuse_block_end = os.environ.get("STLPOSE_FUSE_BLOCK_END", "1") != "0"
         for node in reversed(self.tape):
             kind = node[0]
             if kind == "head":
                 _, x, key, joints = node
+                x.bwd_seen += 1
                 nblk = 256
                 dx = self._new_grad(x)
                 nel = joints * x.C + joints
@@ -346,6 +351,13 @@ class Engine:
                                        nsplit=nblk, Co=joints, Ci=1, ks=1, Cip=1, patch=0, stride=nel))
             elif kind == "fuse":
                 _, terms, z, relu, strm = node
+                for a, _s, _ in terms:
+                    a.bwd_seen += 1
+                if z.fused_du is not None:
+                    # the ReLU mask, the BatchNorm reductions and the sum of contributions were done in the
+                    # epilogue of the data gradient that produced the last contribution (mask_z)
+                    assert not z.grads
+                    z.grads.append(z.fused_du)
                 assert 1 <= len(z.grads) <= 4, f"fuse output has {len(z.grads)} gradient contributions"
                 p = capi.FuseBwd()
                 p.dtype, p.B, p.H, p.W, p.C = self.dtype, z.B, z.H, z.W, z.C
@@ -358,7 +370,7 @@ class Engine:
                 for i, a in enumerate(same_bn):
                     p.bn[i] = self._src(a)
                     p.rstats[i] = self.rstats.data_ptr() + 8 * a.bn.stats_off
-                trivial = (len(z.grads) == 1 and not relu and not same_bn)
+                trivial = (len(z.grads) == 1 and not relu and not same_bn) or z.fused_du is not None
                 du = z.grads[0] if trivial else self._new_grad(z)
                 p.du = du.data_ptr()
                 if not trivial:
@@ -381,6 +393,7 @@ class Engine:
                         ops.append(("stl_upsample_backward", u, strm, [du.data_ptr()], [a.dt.data_ptr()]))
             else:  # conv
                 _, x, y, ci, (kks, kstride), strm = node
+                x.bwd_seen += 1
                 assert y.consumers == 1 and y.dt is not None, f"{ci.key}: BN activation must have exactly one consumer"
                 g = self._gsrc(y)
                 # ---- weight gradient
@@ -439,7 +452,22 @@ class Engine:
                         ad = x.grads.pop()
                         d.addend = ad.data_ptr()
                         dreads.append(ad.data_ptr())
-                    x.grads.append(out)
+                    # Residual block end z = ReLU(BN(y) + skip): when this data gradient is the LAST
+                    # contribution to dz, its epilogue also applies the ReLU mask and reduces the
+                    # BatchNorm-backward sums, so no separate pass over dz / z / y is needed.
+                    F = producer.get(id(x))
+                    same_bn = [a for a, s_, _ in F[1] if a.kind == "bn" and s_ == 0] if F else []
+                    if (fuse_block_end and F is not None and F[3] and len(same_bn) == 1 and not x.grads
+                            and x.bwd_seen == x.consumers):
+                        ybn = same_bn[0]
+                        d.mask_z = x.ptr
+                        d.mask_y = ybn.ptr
+                        d.mask_bn = self._src(ybn, relu=False)
+                        d.red = self.rstats.data_ptr() + 8 * ybn.bn.stats_off
+                        dreads += [x.ptr, ybn.ptr]
+                        x.fused_du = out
+                    else:
+                        x.grads.append(out)
                 else:
                     assert x.dt is None
                     out = self._new_grad(x)

@@ -434,3 +434,50 @@ def test_weight_prep_and_reduce_slabs_tables():
     capi.call("stl_reduce_slabs", partials.data_ptr(), grads.data_ptr(), sdev.data_ptr(), len(shapes), blk, stream())
     torch.cuda.synchronize()
     assert torch.allclose(grads, torch.cat(exp), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 24, 16, 32, 32, 3), (2, 12, 10, 64, 128, 1), (3, 16, 12, 128, 64, 3)])
+def test_conv_block_end_backward_in_epilogue(case, dt):
+    """mask_z: the backward of a residual block end z = ReLU(BN(y) + skip) done in the epilogue of
+    the data gradient that yields the last contribution to dz:
+        du = (conv(g, w) + addend) * (z > 0),  r1 = sum du,  r2 = sum du * yhat(y)
+    -- what stl_fuse_backward computes from a materialised dz (reference HRnet.py:58-59, autograd)."""
+    code, td, tol = DT[dt]
+    B, H, W, Ci, Co, ks = case
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    pad = 1 if ks == 3 else 0
+    g0 = nhwc(torch.randn(B, Ci, H, W, device="cuda", generator=gen), td)
+    w = torch.randn(Co, Ci, ks, ks, device="cuda", generator=gen) / math.sqrt(Ci * ks * ks)
+    wt = w.permute(0, 2, 3, 1).contiguous().to(td)
+    add = nhwc(torch.randn(B, Co, H, W, device="cuda", generator=gen), td)
+    z = nhwc(torch.randn(B, Co, H, W, device="cuda", generator=gen).clamp_min(0), td)
+    y = nhwc(torch.randn(B, Co, H, W, device="cuda", generator=gen) * 1.3 + 0.2, td)
+    gam = torch.rand(Co, device="cuda", generator=gen) + 0.5
+    bet = torch.rand(Co, device="cuda", generator=gen) - 0.5
+    sty = stats_of(y, Co)
+    out = torch.full((B * H * W * Co,), float("nan"), device="cuda", dtype=td)
+    red = torch.zeros(capi.NSHARD * 2 * Co, dtype=torch.float64, device="cuda")
+    d = capi.Conv()
+    d.shape = -1
+    d.dtype, d.B, d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.Co = code, B, H, W, Ci, H, W, Co
+    d.ks, d.stride = ks, 1
+    d.src.x, d.src.mode = g0.data_ptr(), capi.SRC_PLAIN
+    d.w, d.out, d.addend = wt.data_ptr(), out.data_ptr(), add.data_ptr()
+    d.mask_z, d.mask_y = z.data_ptr(), y.data_ptr()
+    d.mask_bn = bn_src(y, sty, gam, bet, B * H * W, False)
+    d.red = red.data_ptr()
+    capi.call("stl_conv_forward", C.byref(d), stream())
+    torch.cuda.synchronize()
+    f = F.conv2d(from_nhwc(g0, B, H, W, Ci), wt.float().permute(0, 3, 1, 2), padding=pad) + from_nhwc(add, B, H, W, Co)
+    ref = torch.where(from_nhwc(z, B, H, W, Co) > 0, f, torch.zeros_like(f))
+    got = from_nhwc(out, B, H, W, Co)
+    assert not torch.isnan(got).any()
+    assert relerr(got, ref) < tol
+    # reductions are those of the STORED gradient
+    du = out.view(-1, Co).double()
+    yf = y.view(-1, Co).double()
+    yhat = (yf - yf.mean(0)) / torch.sqrt(yf.var(0, unbiased=False) + EPS)
+    r = red.view(capi.NSHARD, 2, Co).sum(0)
+    assert relerr(r[0], du.sum(0)) < 1e-4
+    assert relerr(r[1], (du * yhat).sum(0)) < 1e-3
