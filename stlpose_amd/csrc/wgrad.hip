@@ -587,7 +587,9 @@ int dispatch64(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
 int wgrad_chunk(const stl_wgrad& p) {
     // opt-in (STL_WGRAD_64=1): on MI355X the wide variant halves the activation re-reads but, at HRNet's
     // sizes, loses as much again to the 4x larger split-K slabs (23.5 vs 23.7 ms/step, slower in isolation)
-    if (!getenv("STL_WGRAD_64")) return 32;
+    const char* e = getenv("STL_WGRAD_64");
+    if (!e) return 32;
+    if (e[0] == 'k' && p.ks != 1) return 32;  // "k1": 1x1 convolutions only
     return (p.dtype == STL_BF16 && p.stride == 1 && p.Co >= 64 && p.Ci >= 64) ? 64 : 32;
 }
 
