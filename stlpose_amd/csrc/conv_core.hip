@@ -42,6 +42,7 @@ struct ConvK {
     int TH, TW;
     int dbg;
     float r_HC, r_TW, r_tc, r_PI, r_vp;  // reciprocals for fdiv
+    int ny;  // output-channel blocks per pixel tile (they are the FAST block dimension, see kernel)
 };
 
 template <typename T>
@@ -82,7 +83,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     const stl_conv& p = k.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
     const int wm = wave % WM, wn = wave / WM;
-    const int n0 = blockIdx.y * BCO;
+    // Block order: XCD = blockIdx.x & 7; within an XCD the ny channel blocks of one pixel tile are
+    // neighbours, so they run at the same time on the same L2: the input tile is fetched from HBM
+    // once for all of them, and the ny pieces of every output row are written together.
+    const int bl = blockIdx.x >> 3;
+    const int by = bl % k.ny, lx = bl / k.ny;
+    const int n0 = by * BCO;
 
     STAMP(0);
     if (k.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[12] = __builtin_amdgcn_s_memtime();
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 #pragma unroll
         for (int h = 0; h < 2; ++h) s0[ni][h] = f2v{0.f, 0.f}, s1[ni][h] = f2v{0.f, 0.f};
 
-    const int xcd = blockIdx.x & 7, lx = blockIdx.x >> 3, nx = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, nx = (gridDim.x >> 3) / k.ny;
     const int T8 = (k.npt + 7) >> 3;
     const int vpitch = p.Ho + 1;
 
@@ -617,11 +623,12 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     if (const char* e = getenv("STL_CONV_CAP512")) cap = sh.ws ? 256 : (sh.thr == 512 ? atoi(e) : 1024);
     if (const char* e = getenv("STL_CONV_GRID_CAP")) cap = atoi(e) > 0 ? (atoi(e) + 7) / 8 * 8 : cap;
     if (gx > cap) gx = cap;
-    dim3 grid(gx, ceil_div(p.Co, sh.co));
+    k.ny = ceil_div(p.Co, sh.co);
+    dim3 grid(gx * k.ny, 1);
     const int nva = ceil_div(k.HP * 4, sh.lthr);
     if (getenv("STL_CONV_DEBUG"))
-        fprintf(stderr, "[stl conv] %dx%d Ci%d Co%d ks%d s%d: shape=%d tile=%dx%d npt=%d grid=(%d,%d) lds=%zu nva=%d nchunks=%d\n", p.Ho,
-                p.Wo, p.Ci, p.Co, p.ks, p.stride, plan.shape, plan.TH, plan.TW, k.npt, gx, grid.y, lds, nva, k.nchunks);
+        fprintf(stderr, "[stl conv] %dx%d Ci%d Co%d ks%d s%d: shape=%d tile=%dx%d npt=%d grid=(%d x %d) lds=%zu nva=%d nchunks=%d\n", p.Ho,
+                p.Wo, p.Ci, p.Co, p.ks, p.stride, plan.shape, plan.TH, plan.TW, k.npt, gx, k.ny, lds, nva, k.nchunks);
     hipStream_t st = (hipStream_t)stream;
     const bool q = p.src.mode == STL_SRC_BNBWD;
 #define DISPATCH(T)                                                                                      \
