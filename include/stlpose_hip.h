@@ -236,6 +236,15 @@ int stl_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H,
 #define STL_OP_PATCH 5
 #define STL_OP_HEAD 6
 #define STL_OP_HEAD_BWD 7
+#define STL_OP_REDUCE_RANGE 8 /* stl_reduce_slabs over a sub-range of the table (a gradient bucket) */
+#define STL_OP_BN_GRADS_RANGE 9 /* stl_bn_param_grads over a sub-range of the table */
+/* A gradient bucket = a contiguous slice of the flat gradient buffer whose weight-gradient slabs and
+ * BatchNorm reductions are complete at some point of the backward program.  Reducing it there (and
+ * recording an event) lets the data-parallel all-reduce of that slice start while the rest of
+ * backward still runs (reference: the per-step gradient gather of nn.DataParallel, 02_train.py:109). */
+typedef struct stl_reduce_range { const float* partials; float* grads; const stl_slab* tab; int32_t n, blk_base, nblocks, pad_; } stl_reduce_range;
+typedef struct stl_bn_range { const double* rstats; float* grads; const stl_bnrec* tab; int32_t n, pad_; } stl_bn_range;
+int stl_reduce_slabs_range(const stl_reduce_range* r, void* stream);
 typedef struct stl_patch { int32_t dtype, B, H, W, stride, pad_; const float* img; void* out; const float* mean3; const float* std3; } stl_patch;
 typedef struct stl_head { int32_t dtype, B, H, W, Ci, J; const void* x; const float* w; const float* bias; float* out; } stl_head;
 typedef struct stl_head_bwd { int32_t dtype, B, H, W, Ci, J, nblk, pad_; const void* x; const float* w; const float* dout; void* dx; float* partial; } stl_head_bwd;
@@ -244,12 +253,15 @@ typedef struct stl_op {
     int32_t stream;  /* index into the streams array given to run()      */
     const void* desc; /* the op's descriptor struct (kept alive by the caller) */
     int32_t nwait;
-    int32_t wait[6];
+    int32_t wait[8];
     int32_t record;  /* 1: record an event after this op (someone waits on it) */
 } stl_op;
 int stl_program_create(const stl_op* ops, int n, int nstreams, void** out_handle);
 int stl_program_run(void* program, void* const* streams /* hipStream_t[nstreams]; [0] = main */);
 int stl_program_destroy(void* program);
+/* Make `stream` wait for op `op` (which must record) of the LAST run of the program: how a
+ * communication stream picks up a finished gradient bucket. */
+int stl_program_wait_op(void* program, int op, void* stream);
 
 /* Self-checks that need no reference: MFMA / LDS-transpose lane maps (used by tests). */
 int stl_selftest_mfma(float* out /* [4] max abs err: bf16 mfma, f32 mfma, tr-read, f64 atomic */, void* stream);

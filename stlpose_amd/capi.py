@@ -84,11 +84,20 @@ class HeadBwd(C.Structure):
 
 
 class Op(C.Structure):
-    _fields_ = [("kind", i32), ("stream", i32), ("desc", vp), ("nwait", i32), ("wait", i32 * 6), ("record", i32)]
+    _fields_ = [("kind", i32), ("stream", i32), ("desc", vp), ("nwait", i32), ("wait", i32 * 8), ("record", i32)]
+
+
+class ReduceRange(C.Structure):
+    _fields_ = [("partials", vp), ("grads", vp), ("tab", vp), ("n", i32), ("blk_base", i32), ("nblocks", i32), ("pad_", i32)]
+
+
+class BNRange(C.Structure):
+    _fields_ = [("rstats", vp), ("grads", vp), ("tab", vp), ("n", i32), ("pad_", i32)]
 
 
 OP_KIND = {"stl_conv_forward": 0, "stl_conv_wgrad": 1, "stl_fuse_forward": 2, "stl_fuse_backward": 3,
-           "stl_upsample_backward": 4, "stl_patch3x3": 5, "stl_head_forward": 6, "stl_head_backward": 7}
+           "stl_upsample_backward": 4, "stl_patch3x3": 5, "stl_head_forward": 6, "stl_head_backward": 7,
+           "stl_reduce_slabs_range": 8, "stl_bn_grads_range": 9}
 
 # name -> argtypes (restype is always int unless noted); every symbol include/stlpose_hip.h declares
 SIGNATURES = {
@@ -111,6 +120,7 @@ SIGNATURES = {
     "stl_final_preds": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "stl_weight_prep": [i32, vp, vp, vp, i32, i32, vp],
     "stl_reduce_slabs": [vp, vp, vp, i32, i32, vp],
+    "stl_reduce_slabs_range": [C.POINTER(ReduceRange), vp],
     "stl_bn_running_update": [vp, vp, vp, vp, i32, f32, vp],
     "stl_bn_param_grads": [vp, vp, vp, i32, vp],
     "stl_adam_step": [vp, vp, vp, vp, i64, vp, vp, vp],
@@ -124,6 +134,7 @@ SIGNATURES = {
     "stl_program_create": [C.POINTER(Op), i32, i32, C.POINTER(vp)],
     "stl_program_run": [vp, C.POINTER(vp)],
     "stl_program_destroy": [vp],
+    "stl_program_wait_op": [vp, i32, vp],
     "stl_selftest_mfma": [vp, vp],
     "stl_version": [],
 }

@@ -486,14 +486,15 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* master, T
     }
 }
 
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* partials, float* grads, const stl_slab* tab, int n) {
-    const int ei = find_entry(&tab[0].blk0, sizeof(stl_slab) / 4, n, blockIdx.x);
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* partials, float* grads, const stl_slab* tab, int n, int blk_base) {
+    const int bx = blockIdx.x + blk_base;  // tab points at the first entry of the range, blk0 values are table-absolute
+    const int ei = find_entry(&tab[0].blk0, sizeof(stl_slab) / 4, n, bx);
     const stl_slab e = tab[ei];
     const int t = e.ks * e.ks;
     const int64_t tot = (int64_t)e.Co * e.Ci * t;
     const int tk = e.patch ? 1 : t, cik = e.patch ? e.Cip : e.Ci;
     const int64_t slab = e.pad ? (int64_t)e.pad : (int64_t)e.Co * tk * cik;
-    const int64_t base = (int64_t)(blockIdx.x - e.blk0) * 1024;
+    const int64_t base = (int64_t)(bx - e.blk0) * 1024;
     if (!e.patch && (e.Ci & 3) == 0) {
         // fast path: walk the slabs in THEIR order ([Co][taps][Ci], 16-byte coalesced reads, four slabs
         // in flight), scatter the four sums into the OIHW gradient (1/nsplit of the traffic)
@@ -930,8 +931,16 @@ extern "C" int stl_weight_prep(int dtype, const float* master, void* wk, const s
 
 extern "C" int stl_reduce_slabs(const float* partials, float* grads, const stl_slab* tab, int n, int nblocks, void* stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(nblocks), dim3(256), 0, ST, partials, grads, tab, n);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(nblocks), dim3(256), 0, ST, partials, grads, tab, n, 0);
     STL_LAUNCH_CHECK("reduce_slabs");
+    return 0;
+}
+
+extern "C" int stl_reduce_slabs_range(const stl_reduce_range* r, void* stream) {
+    STL_CHECK(r && r->partials && r->grads && r->tab && r->n >= 0 && r->nblocks >= 0, "reduce_slabs_range: bad arguments");
+    if (r->n == 0 || r->nblocks == 0) return 0;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(r->nblocks), dim3(256), 0, ST, r->partials, r->grads, r->tab, r->n, r->blk_base);
+    STL_LAUNCH_CHECK("reduce_slabs_range");
     return 0;
 }
 

@@ -23,7 +23,7 @@ extern "C" int stl_program_create(const stl_op* ops, int n, int nstreams, void**
     p->ev_of.assign(n, -1);
     for (int i = 0; i < n; ++i) {
         const stl_op& o = ops[i];
-        if (o.stream < 0 || o.stream >= nstreams || o.nwait < 0 || o.nwait > 6 || !o.desc) {
+        if (o.stream < 0 || o.stream >= nstreams || o.nwait < 0 || o.nwait > 8 || !o.desc) {
             delete p;
             return stl_set_error("program_create: op %d malformed (stream %d, nwait %d)", i, o.stream, o.nwait);
         }
@@ -56,6 +56,13 @@ extern "C" int stl_program_destroy(void* h) {
     for (hipEvent_t e : p->join) (void)hipEventDestroy(e);
     if (p->fork) (void)hipEventDestroy(p->fork);
     delete p;
+    return 0;
+}
+
+extern "C" int stl_program_wait_op(void* h, int op, void* stream) {
+    Program* p = static_cast<Program*>(h);
+    STL_CHECK(p && op >= 0 && op < (int)p->ops.size() && p->ev_of[op] >= 0, "program_wait_op: op %d does not record an event", op);
+    STL_CHECK(hipStreamWaitEvent((hipStream_t)stream, p->ev[p->ev_of[op]], 0) == hipSuccess, "program_wait_op: wait failed");
     return 0;
 }
 
@@ -94,6 +101,12 @@ extern "C" int stl_program_run(void* h, void* const* streams) {
             case STL_OP_HEAD_BWD: {
                 const stl_head_bwd* a = static_cast<const stl_head_bwd*>(o.desc);
                 rc = stl_head_backward(a->dtype, a->x, a->w, a->dout, a->dx, a->partial, a->nblk, a->B, a->H, a->W, a->Ci, a->J, st);
+                break;
+            }
+            case STL_OP_REDUCE_RANGE: rc = stl_reduce_slabs_range(static_cast<const stl_reduce_range*>(o.desc), st); break;
+            case STL_OP_BN_GRADS_RANGE: {
+                const stl_bn_range* a = static_cast<const stl_bn_range*>(o.desc);
+                rc = stl_bn_param_grads(a->rstats, a->grads, a->tab, a->n, st);
                 break;
             }
             default: return stl_set_error("program_run: op %d has unknown kind %d", i, o.kind);

@@ -17,21 +17,26 @@ import torch.distributed as dist
 
 
 class FlatAllReduce:
-    def __init__(self, flat: torch.Tensor, process_group=None, bucket_mb: float = 32.0):
+    def __init__(self, flat: torch.Tensor, process_group=None, bucket_mb: float = 32.0, bounds=None):
         self.flat = flat
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         n = flat.numel()
-        nb = max(1, int(round(n * flat.element_size() / (bucket_mb * 2 ** 20))))
-        edges = [int(round(i * n / nb)) for i in range(nb + 1)]
-        # reversed: the tail of the buffer (last layers) is ready first in backward
-        self.bounds = [(edges[i], edges[i + 1]) for i in reversed(range(nb))]
+        if bounds is not None:
+            # the engine's gradient buckets, in the order backward completes them (engine.buckets)
+            self.bounds = [(int(a), int(b)) for a, b in bounds]
+            assert sorted(self.bounds) == sorted(set(self.bounds)) and sum(b - a for a, b in self.bounds) == n
+        else:
+            nb = max(1, int(round(n * flat.element_size() / (bucket_mb * 2 ** 20))))
+            edges = [int(round(i * n / nb)) for i in range(nb + 1)]
+            # reversed: the tail of the buffer (last layers) is ready first in backward
+            self.bounds = [(edges[i], edges[i + 1]) for i in reversed(range(nb))]
         self.buckets: List[torch.Tensor] = [flat[a:b] for a, b in self.bounds]
         self._works: List = []
 
-    def launch(self, upto: Optional[int] = None):
+    def launch(self, upto: Optional[int] = None, force: bool = False):
         """Start async all-reduces for buckets [len(started), upto)."""
-        if self.world == 1:
+        if self.world == 1 and not force:
             return
         upto = len(self.buckets) if upto is None else upto
         for b in self.buckets[len(self._works):upto]:

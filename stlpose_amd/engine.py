@@ -171,9 +171,9 @@ class Engine:
         self._wk_fix: List[Tuple] = []
         walk(self, arch)
         self._finalize_weights()
+        self._build_tables()
         if training:
             self._build_backward()
-        self._build_tables()
 
     # ------------------------------------------------------------------ allocation helpers
     def _alloc(self, nbytes: int) -> torch.Tensor:
@@ -329,8 +329,34 @@ class Engine:
         self.dout = torch.zeros_like(self.out)
         producer = {id(n[2]): n for n in self.tape if n[0] == "fuse"}
         fuse_block_end = os.environ.get("STLPOSE_FUSE_BLOCK_END", "1") != "0"
+        # ---- gradient buckets: contiguous suffixes of the flat gradient buffer, closed as soon as every
+        # parameter in them has its slabs / BatchNorm reductions complete (backward finishes the last
+        # layers first).  Each bucket gets one ranged slab reduction + BN-gradient launch inside the
+        # program, so the step has no serial tail, and an event a data-parallel all-reduce can wait on.
+        self.buckets: List[dict] = []
+        bucket_min = int(float(os.environ.get("STLPOSE_BUCKET_MB", "16")) * (1 << 20) / 4)
+        bk = dict(done=0, lo=st.nparam, hi=st.nparam, slab0=0, reads=[], strm=0)
+
+        def bucket_add(off: int, size: int):
+            bk["done"] += size
+            bk["lo"] = min(bk["lo"], off)
+
+        def bucket_close(force: bool = False):
+            complete = bk["done"] == bk["hi"] - bk["lo"]          # suffix [lo, hi) fully covered
+            if not complete or bk["done"] == 0 or (bk["done"] < bucket_min and not force):
+                return
+            assert complete
+            rr, br = capi.ReduceRange(), capi.BNRange()
+            b = dict(lo=bk["lo"], hi=bk["hi"], slab0=bk["slab0"], slab1=len(self.slabs), rr=rr, br=br)
+            wstrm = bk["strm"]
+            ops.append(("stl_reduce_slabs_range", rr, wstrm, list(bk["reads"]), [("bucket", len(self.buckets))]))
+            ops.append(("stl_bn_grads_range", br, wstrm, [("bucket", len(self.buckets))], [("bucketbn", len(self.buckets))]))
+            b["op"] = len(ops) - 1
+            self.buckets.append(b)
+            bk.update(done=0, hi=bk["lo"], slab0=len(self.slabs), reads=[])
         for node in reversed(self.tape):
             kind = node[0]
+            bucket_close()   # after the previous node's ops: closes a bucket when a complete suffix is large enough
             if kind == "head":
                 _, x, key, joints = node
                 x.bwd_seen += 1
@@ -343,7 +369,10 @@ class Engine:
                 hb.dtype, hb.B, hb.H, hb.W, hb.Ci, hb.J, hb.nblk = self.dtype, x.B, x.H, x.W, x.C, joints, nblk
                 hb.x, hb.w, hb.dout, hb.dx = x.ptr, self.head_w, self.dout.data_ptr(), dx.data_ptr()
                 self._head_bwd_args = (hb, part_off)
-                ops.append(("stl_head_backward", hb, 0, [self.dout.data_ptr(), x.ptr], [dx.data_ptr()]))
+                ops.append(("stl_head_backward", hb, 0, [self.dout.data_ptr(), x.ptr], [dx.data_ptr(), id(hb)]))
+                bk["reads"].append(id(hb))
+                bucket_add(st.param_off[key + ".weight"], joints * x.C)
+                bucket_add(st.param_off[key + ".bias"], joints)
                 x.grads.append(dx)
                 self.slabs.append(dict(part_off=part_off, grad_off=st.param_off[key + ".weight"], nsplit=nblk,
                                        Co=joints, Ci=x.C, ks=1, Cip=x.C, patch=0, stride=nel))
@@ -433,6 +462,10 @@ class Engine:
                 # them their own streams so they overlap with the chain
                 wstrm = (self.nstreams + strm % self.nwstreams) if self.wgrad_streams else strm
                 ops.append(("stl_conv_wgrad", wg, wstrm, [y.dt.data_ptr(), x.ptr], [id(wg)]))
+                bk["reads"].append(id(wg))
+                bk["strm"] = wstrm
+                bucket_add(ci.master_off, ci.Co * ci.Ci * ci.ks * ci.ks)
+                bucket_add(y.bn.param_off, 2 * y.bn.C)   # gamma, beta of the BatchNorm behind this conv
                 # ---- data gradient
                 if not x.needs_grad:
                     continue
@@ -477,6 +510,8 @@ class Engine:
                     d.red = self.rstats.data_ptr() + 8 * x.bn.stats_off
                 d.out = out.data_ptr()
                 ops.append(("stl_conv_forward", d, strm, dreads, [out.data_ptr()]))
+        bucket_close(force=True)
+        assert bk["done"] == 0 and bk["hi"] == 0, "gradient buckets do not cover the parameter buffer"
         # slab arena + reduce table
         self.slab_arena = torch.empty(max(self._slab_elems, 1), dtype=torch.float32, device=self.dev)
         base = self.slab_arena.data_ptr()
@@ -494,6 +529,18 @@ class Engine:
             blk += math.ceil(s["Co"] * s["Ci"] * s["ks"] * s["ks"] / 1024)
         self._slab_blocks, self._slab_n = blk, len(self.slabs)
         self._slab_tab = _to_device(tab, self.dev)
+        blk0 = [tab[i].blk0 for i in range(len(self.slabs))] + [blk]
+        bn_off = [b_.param_off for b_ in self.bns]            # forward (= ascending offset) order
+        assert bn_off == sorted(bn_off)
+        import bisect
+        for b in self.buckets:
+            rr, br = b["rr"], b["br"]
+            rr.partials, rr.grads = self.slab_arena.data_ptr(), st.grads.data_ptr()
+            rr.tab = self._slab_tab.data_ptr() + b["slab0"] * C.sizeof(capi.Slab)
+            rr.n, rr.blk_base, rr.nblocks = b["slab1"] - b["slab0"], blk0[b["slab0"]], blk0[b["slab1"]] - blk0[b["slab0"]]
+            i0, i1 = bisect.bisect_left(bn_off, b["lo"]), bisect.bisect_left(bn_off, b["hi"])
+            br.rstats, br.grads = self.rstats.data_ptr(), st.grads.data_ptr()
+            br.tab, br.n = self._bn_tab.data_ptr() + i0 * C.sizeof(capi.BNRec), i1 - i0
         self.bwd_ops = ops
 
     def _build_tables(self):
@@ -515,10 +562,15 @@ class Engine:
                 j = last.get(r)
                 if j is not None and ops[j][2] != st_:
                     w.add(j)
-                    need.add(j)
+            latest = {}
+            for j in w:                      # streams are in-order: the latest producer per stream covers the others
+                latest[ops[j][2]] = max(latest.get(ops[j][2], -1), j)
+            w = set(latest.values())
+            need.update(w)
             waits.append(sorted(w))
             for t in writes:
                 last[t] = i
+        need.update(b["op"] for b in getattr(self, "buckets", []) if ops is self.bwd_ops)
         return waits, need
 
     def _program(self, ops):
@@ -531,7 +583,7 @@ class Engine:
             for i, (name, desc, st_, _, _) in enumerate(ops):
                 o = arr[i]
                 o.kind, o.stream, o.desc = capi.OP_KIND[name], st_, C.addressof(desc)
-                assert len(waits[i]) <= 6, "op waits on more than 6 producers"
+                assert len(waits[i]) <= 8, "op waits on more than 8 producers"
                 o.nwait = len(waits[i])
                 for j, wv in enumerate(waits[i]):
                     o.wait[j] = wv
@@ -581,10 +633,12 @@ class Engine:
         assert self.training
         st = self.store
         self.rstats.zero_()
-        self._run(self.bwd_ops, stream)
-        capi.call("stl_bn_param_grads", self.rstats.data_ptr(), st.grads.data_ptr(), self._bn_tab.data_ptr(), len(self.bns), stream)
-        capi.call("stl_reduce_slabs", self.slab_arena.data_ptr(), st.grads.data_ptr(), self._slab_tab.data_ptr(),
-                  self._slab_n, self._slab_blocks, stream)
+        self._run(self.bwd_ops, stream)   # includes the per-bucket slab reductions and BatchNorm gradients
+
+    def bucket_wait(self, i: int, stream: int):
+        """Make `stream` wait until gradient bucket i (self.buckets[i]: flat slice [lo, hi)) of the
+        backward pass enqueued last is final."""
+        capi.call("stl_program_wait_op", self._program(self.bwd_ops), self.buckets[i]["op"], stream)
 
 
 def _is_bn_weight(key: str, reg: Registry) -> bool:

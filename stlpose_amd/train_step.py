@@ -37,7 +37,11 @@ class TrainStep:
         self.eng = model.engine(batch, height, width, True)
         self.kind = optimizer
         self.pg = process_group
-        self.dp = FlatAllReduce(self.store.grads, process_group, bucket_mb) if process_group is not None else None
+        # buckets = the engine's own gradient buckets (contiguous slices, final at known points of backward)
+        self.dp = (FlatAllReduce(self.store.grads, process_group, bucket_mb, bounds=[(b["lo"], b["hi"]) for b in self.eng.buckets])
+                   if process_group is not None else None)
+        self._comm: Optional[torch.cuda.Stream] = None
+        self._force_dp = os.environ.get("STLPOSE_DP_FORCE", "0") == "1"   # exercise the DP path with one rank (tests)
         self.world = self.dp.world if self.dp is not None else 1
         n = self.store.nparam
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -89,8 +93,20 @@ class TrainStep:
                       self.hyper.data_ptr(), self.step_count.data_ptr(), st)
 
     def _allreduce(self):
-        if self.dp is not None and self.world > 1:
-            self.dp.all_reduce()
+        """Bucketed all-reduce overlapped with backward: the backward program is already ENQUEUED when
+        this runs; every bucket's collective is issued on a communication stream that waits for the
+        event recorded after that bucket's slab reduction, so RCCL works on the last layers'
+        gradients while the data-gradient chain is still in the early layers.  The main stream then
+        waits for all collectives before the optimiser."""
+        if self.dp is None or (self.world == 1 and not self._force_dp):
+            return
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=self.dev)
+        for i in range(len(self.eng.buckets)):
+            self.eng.bucket_wait(i, self._comm.cuda_stream)
+            with torch.cuda.stream(self._comm):
+                self.dp.launch(upto=i + 1, force=self._force_dp)
+        self.dp.wait()
 
     def _capture(self):
         side = torch.cuda.Stream()

@@ -68,3 +68,41 @@ def test_sgd_nesterov_step_runs():
     for _ in range(10):
         l = float(ts.step().item())
     assert np.isfinite(l) and l < l0
+
+
+def test_gradient_buckets_cover_the_flat_buffer_and_dp_path_matches(monkeypatch):
+    """The backward program reduces the weight-gradient slabs bucket by bucket (no serial tail) and
+    records an event per bucket; the data-parallel path all-reduces each bucket on a communication
+    stream as soon as that event fires.  With ONE rank (RCCL all-reduce = identity) the bucketed path
+    must give exactly the gradients and losses of the plain path."""
+    import torch.distributed as dist
+    torch.manual_seed(5)
+    img, tgt, tw = _batch(4, 256, 192, seed=7)
+
+    def run(dp):
+        torch.manual_seed(11)
+        m = PoseHighResolutionNet("w32", "bf16").cuda()
+        pg = None
+        if dp:
+            if not dist.is_initialized():
+                dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1)
+            pg = dist.group.WORLD
+            monkeypatch.setenv("STLPOSE_DP_FORCE", "1")
+        ts = TrainStep(m, 4, 256, 192, optimizer="sgd", lr=1e-2, process_group=pg)
+        ts.load_batch(img.cuda(), tgt.cuda(), tw.cuda())
+        losses = [float(ts.step().item()) for _ in range(3)]
+        torch.cuda.synchronize()
+        return ts, losses, ts.store.grads.clone(), ts.store.master.clone()
+
+    ts0, l0, g0, w0 = run(False)
+    bk = ts0.eng.buckets
+    assert len(bk) >= 3
+    # buckets tile the flat parameter buffer from the back (last layers first), without gaps
+    assert bk[0]["hi"] == ts0.store.nparam and bk[-1]["lo"] == 0
+    assert all(bk[i]["lo"] == bk[i + 1]["hi"] for i in range(len(bk) - 1))
+    ts1, l1, g1, w1 = run(True)
+    assert ts1.dp is not None and len(ts1.dp.buckets) == len(bk)
+    assert l0 == l1
+    assert torch.equal(g0, g1) and torch.equal(w0, w1)
+    if dist.is_initialized():
+        dist.destroy_process_group()

@@ -35,17 +35,18 @@ def test_struct_sizes_match_header(built_lib):
     import subprocess
     import tempfile
     from stlpose_amd import capi
-    src = '#include <stdio.h>\n#include "stlpose_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",' \
+    src = '#include <stdio.h>\n#include "stlpose_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",' \
           'sizeof(stl_src),sizeof(stl_conv),sizeof(stl_wgrad),sizeof(stl_term),sizeof(stl_fuse),sizeof(stl_fuse_bwd),' \
           'sizeof(stl_upbwd),sizeof(stl_wprep),sizeof(stl_slab),sizeof(stl_bnrec),sizeof(stl_patch),sizeof(stl_head),' \
-          'sizeof(stl_head_bwd),sizeof(stl_op));return 0;}'
+          'sizeof(stl_head_bwd),sizeof(stl_op),sizeof(stl_reduce_range),sizeof(stl_bn_range));return 0;}'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
         sizes = list(map(int, subprocess.check_output([os.path.join(d, "s")]).split()))
     import ctypes
     mine = [ctypes.sizeof(c) for c in (capi.Src, capi.Conv, capi.Wgrad, capi.Term, capi.Fuse, capi.FuseBwd, capi.UpBwd,
-                                       capi.WPrep, capi.Slab, capi.BNRec, capi.Patch, capi.Head, capi.HeadBwd, capi.Op)]
+                                       capi.WPrep, capi.Slab, capi.BNRec, capi.Patch, capi.Head, capi.HeadBwd, capi.Op,
+                                       capi.ReduceRange, capi.BNRange)]
     assert mine == sizes
 
 
