@@ -1,0 +1,88 @@
+"""GPU: the 02_train.py counterpart (stlpose_amd/trainer.py) -- epoch structure, training_logs.json,
+checkpoint layout of the reference (module. prefix, torch.optim-shaped optimizer state), resume."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from stlpose_amd.trainer import Trainer  # noqa: E402
+
+
+def _loader(n, B, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    hh, ww = H // 4, W // 4
+    out = []
+    for _ in range(n):
+        img = torch.randn(B, 3, H, W, generator=g)
+        cx = torch.randint(2, ww - 2, (B, 17, 1, 1), generator=g).float()
+        cy = torch.randint(2, hh - 2, (B, 17, 1, 1), generator=g).float()
+        ys, xs = torch.arange(hh).view(1, 1, hh, 1).float(), torch.arange(ww).view(1, 1, 1, ww).float()
+        tgt = torch.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) / 8.0)
+        tw = (torch.rand(B, 17, 1, generator=g) < 0.8).float()
+        out.append((img, tgt, tw, {"perceptual_loss": torch.zeros(B)}))
+    return out
+
+
+def _exp_data(epochs, H, W, optimizer="adam", scheduler="step"):
+    return {"training": {"num_epochs": epochs, "save_frequency": 1, "learning_rate": 1e-3, "learning_rate_factor": 0.5,
+                         "patience": 1, "momentum": 0.9, "optimizer": optimizer, "nesterov": False, "scheduler": scheduler},
+            "model": {"model_name": "HRNet"}, "dataset": {"image_size": [H, W], "dataset_name": "coco"}}
+
+
+def test_trainer_epochs_logs_checkpoints_and_resume(tmp_path):
+    B, H, W = 4, 96, 64
+    train, valid = _loader(6, B, H, W, 1), _loader(10, B, H, W, 2)
+    exp_a = str(tmp_path / "a")
+    os.makedirs(exp_a)
+    torch.manual_seed(3)
+    ta = Trainer(exp_a, _exp_data(2, H, W), train, valid, B, arch="tiny", compute_dtype="fp32")
+    ta.setup_model()
+    ta.training_loop()
+    logs = json.load(open(os.path.join(exp_a, "training_logs.json")))
+    assert set(logs) == {"last_modified", "iterations", "loss", "accuracy"} and logs["iterations"] == 12
+    assert len(logs["loss"]["training"]) == 2 and len(logs["accuracy"]["validation"]) == 2
+    assert logs["loss"]["training"][1] < logs["loss"]["training"][0]
+    assert ta.lr == pytest.approx(1e-3 * 0.5 ** 2)          # StepLR, step_size 1, two epochs
+    # checkpoint layout of the reference (model_setup.py:200-205; DataParallel prefix 02_train.py:166)
+    names = sorted(os.listdir(os.path.join(exp_a, "models")))
+    assert names == ["checkpoint_epoch_0.pth", "checkpoint_epoch_1.pth", "checkpoint_epoch_final.pth"]
+    ck = torch.load(os.path.join(exp_a, "models", "checkpoint_epoch_0.pth"), weights_only=False)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict"}
+    assert all(k.startswith("module.") for k in ck["model_state_dict"])
+    # the optimizer state is what torch.optim.Adam over the same parameter list would save
+    params = [torch.nn.Parameter(torch.zeros_like(p)) for p in ta.model.parameters()]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    opt.load_state_dict(ck["optimizer_state_dict"])
+    assert opt.state[params[0]]["exp_avg"].shape == params[0].shape
+    assert float(opt.state[params[-1]]["step"]) == 6.0
+    # resume from epoch 0's checkpoint: epoch 1 is replayed and ends where the straight run ended
+    exp_b = str(tmp_path / "b")
+    os.makedirs(exp_b)
+    json.dump(json.load(open(os.path.join(exp_a, "training_logs.json"))), open(os.path.join(exp_b, "training_logs.json"), "w"))
+    tb = Trainer(exp_b, _exp_data(2, H, W), train, valid, B, arch="tiny", compute_dtype="fp32",
+                 checkpoint=os.path.join(exp_a, "models", "checkpoint_epoch_0.pth"), resume_training=True)
+    tb.setup_model()
+    assert tb.cur_epoch == 0 and int(tb.ts.step_count.item()) == 6
+    tb.cur_epoch = 1                                        # the checkpoint was written AFTER epoch 0 finished
+    tb.training_loop()
+    wa = torch.cat([p.detach().flatten() for p in ta.model.parameters()])
+    wb = torch.cat([p.detach().flatten() for p in tb.model.parameters()])
+    assert float((wa - wb).abs().max()) < 2e-4 * float(wa.abs().max())
+
+
+def test_trainer_plateau_scheduler_and_sgd(tmp_path):
+    B, H, W = 2, 96, 64
+    exp = str(tmp_path / "c")
+    os.makedirs(exp)
+    t = Trainer(exp, _exp_data(2, H, W, optimizer="sgd", scheduler="plateau"), _loader(3, B, H, W, 4), _loader(5, B, H, W, 5), B,
+                arch="tiny", compute_dtype="bf16")
+    t.setup_model()
+    t.training_loop()
+    assert np.isfinite(t.train_loss) and np.isfinite(t.valid_loss)
+    ck = torch.load(os.path.join(exp, "models", "checkpoint_epoch_final.pth"), weights_only=False)
+    assert "momentum_buffer" in ck["optimizer_state_dict"]["state"][0]
+    assert ck["scheduler_state_dict"]["mode"] == "max"      # the reference steps ReduceLROnPlateau(mode="max") on the loss
