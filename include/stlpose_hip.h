@@ -153,6 +153,13 @@ int stl_head_forward(int dtype, const void* x, const float* w, const float* bias
 int stl_head_backward(int dtype, const void* x, const float* w, const float* dout, void* dx,
                       float* partial, int nblk, int B, int H, int W, int Ci, int J, void* stream);
 
+/* Gaussian heatmap targets on device (reference data/JointsDataset.py:230-286 generate_target):
+ * joints_xy [B][J][2] in image pixels, vis [B][J] in {0,1} -> target [B][J][Hh][Wh] (unnormalised
+ * gaussian, centre value 1, support 3*sigma, clipped at the border), tweight [B][J] (vis, or 0 when
+ * the gaussian lies completely outside the map).  stride = image_size / heatmap_size per axis. */
+int stl_gaussian_targets(const float* joints_xy, const float* vis, float* target, float* tweight, int B, int J,
+                         int Hh, int Wh, float stride_x, float stride_y, float sigma, void* stream);
+
 /* PersonMSELoss forward+backward (reference lib/loss.py:71-94):
  * loss = 0.5*mean(((o-t)*w)^2) over all B*J*H*W;  dout = (o-t)*w^2 / (B*J*H*W) * gscale. */
 int stl_mse_loss(const float* out, const float* target, const float* tweight, float* dout,

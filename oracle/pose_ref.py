@@ -2,7 +2,7 @@
 
 CPU restatement (numpy / plain torch fp32) of the per-batch glue around the network:
 masked MSE loss, flip-test forward, heatmap decode, PCK accuracy, gaussian targets.
-Each function names the reference lines it follows.  Pinned by tests/golden (G5-G7) except
+Each function names the reference lines it follows.  Pinned by tests/golden (G5-G7, G9) except
 ``accuracy`` (reference metrics.py:355-356 is a corrupted line; read as
 ``acc[i + 1] = dist_acc(dists[idx[i]])``, consistent with :357-358) -- parity unpinned.
 """

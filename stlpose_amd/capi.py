@@ -115,6 +115,7 @@ SIGNATURES = {
     "stl_head_forward": [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "stl_head_backward": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "stl_mse_loss": [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, f32, vp],
+    "stl_gaussian_targets": [vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, f32, vp],
     "stl_heatmap_argmax": [vp, vp, vp, vp, i32, i32, i32, vp],
     "stl_flip_merge": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "stl_final_preds": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],

@@ -286,5 +286,40 @@ def main():
     print("G6/G7 done; fixtures in", HERE)
 
 
+def gen_g9():
+    """G9: JointsDataset.generate_target (data/JointsDataset.py:230-286) called on the reference's own
+    class (file loaded directly: data/__init__.py pulls in pycocotools) with a stand-in `self`."""
+    import importlib.util
+    tmp = tempfile.mkdtemp()
+    if "CONFIG" not in sys.modules:
+        _install_shims(tmp)
+    spec = importlib.util.spec_from_file_location("ref_joints_dataset", os.path.join(REF, "data", "JointsDataset.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.Generator(np.random.PCG64(99))
+    out = {}
+    for tag, sigma, hm, img in (("s2", 2, (48, 64), (192, 256)), ("s3", 3, (72, 96), (288, 384))):
+        me = types.SimpleNamespace(num_joints=17, target_type="gaussian", heatmap_size=np.array(hm), image_size=np.array(img),
+                                   sigma=sigma, use_different_joints_weight=False)
+        B = 5
+        joints = np.zeros((B, 17, 3))
+        joints[..., :2] = (rng.uniform(-40, 1.15 * max(img), size=(B, 17, 2)) * 4).round() / 4
+        joints[0, 0, :2] = [0.0, 0.0]
+        joints[0, 1, :2] = [img[0] - 1, img[1] - 1]
+        joints[0, 2, :2] = [-1000.0, 50.0]
+        joints[0, 3, :2] = [img[0] + 3 * sigma * 4 + 8, 10.0]
+        vis = np.zeros((B, 17, 3))
+        vis[..., 0] = vis[..., 1] = (rng.uniform(size=(B, 17)) < 0.8)
+        tg, tw = zip(*[mod.JointsDataset.generate_target(me, joints[b], vis[b]) for b in range(B)])
+        out.update({f"{tag}_joints": joints, f"{tag}_vis": vis, f"{tag}_target": np.stack(tg), f"{tag}_tw": np.stack(tw),
+                    f"{tag}_cfg": np.array([sigma, *hm, *img], np.float64)})
+    np.savez_compressed(os.path.join(HERE, "g9_targets.npz"), **out)
+    print("G9 done")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "g9":
+        gen_g9()
+    else:
+        main()
+        gen_g9()

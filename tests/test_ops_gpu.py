@@ -481,3 +481,42 @@ def test_conv_block_end_backward_in_epilogue(case, dt):
     r = red.view(capi.NSHARD, 2, Co).sum(0)
     assert relerr(r[0], du.sum(0)) < 1e-4
     assert relerr(r[1], (du * yhat).sum(0)) < 1e-3
+
+
+@pytest.mark.parametrize("sigma,hm,img", [(2.0, (48, 64), (192, 256)), (3.0, (72, 96), (288, 384))])
+def test_gaussian_targets_match_oracle(sigma, hm, img):
+    """Device target generation vs the oracle restatement of JointsDataset.generate_target
+    (data/JointsDataset.py:230-286): joints inside, on the border, far outside, invisible."""
+    from oracle import pose_ref
+    from stlpose_amd.targets import generate_targets
+    rng = np.random.default_rng(4)
+    B, J = 6, 17
+    joints = (rng.uniform(-40, 1.15 * max(img), size=(B, J, 2)) * 4).round() / 4     # exactly representable in fp32
+    joints[0, 0] = [0.0, 0.0]
+    joints[0, 1] = [img[0] - 1, img[1] - 1]
+    joints[0, 2] = [-1000.0, 50.0]
+    joints[0, 3] = [img[0] + 3 * sigma * 4 + 8, 10.0]
+    vis = (rng.uniform(size=(B, J)) < 0.8).astype(np.float32)
+    tgt, tw = generate_targets(torch.from_numpy(joints.astype(np.float32)), torch.from_numpy(vis), hm, img, sigma)
+    torch.cuda.synchronize()
+    assert tgt.shape == (B, J, hm[1], hm[0]) and tw.shape == (B, J, 1)
+    for b in range(B):
+        rt, rw = pose_ref.gaussian_targets(joints[b], vis[b], hm, img, sigma)
+        assert np.array_equal(tw[b].cpu().numpy(), rw), b                     # weights are exact
+        assert np.abs(tgt[b].cpu().numpy() - rt).max() < 2e-7, b               # expf vs np.exp (f32): < 2 ulp at 1.0
+        assert np.array_equal(tgt[b].cpu().numpy() > 0, rt > 0), b           # identical support
+
+
+def test_gaussian_targets_match_reference_golden(golden_dir):
+    """Device target generation vs the reference's own generate_target outputs (fixture G9)."""
+    import os
+    from stlpose_amd.targets import generate_targets
+    g = np.load(os.path.join(golden_dir, "g9_targets.npz"))
+    for tag in ("s2", "s3"):
+        sigma, wh, hh, wi, hi = g[f"{tag}_cfg"]
+        tgt, tw = generate_targets(torch.from_numpy(g[f"{tag}_joints"]), torch.from_numpy(g[f"{tag}_vis"]), (int(wh), int(hh)),
+                                   (int(wi), int(hi)), float(sigma))
+        torch.cuda.synchronize()
+        assert np.array_equal(tw.cpu().numpy(), g[f"{tag}_tw"])
+        assert np.abs(tgt.cpu().numpy() - g[f"{tag}_target"]).max() < 2e-7
+        assert np.array_equal(tgt.cpu().numpy() > 0, g[f"{tag}_target"] > 0)

@@ -145,3 +145,17 @@ def test_pck_self_consistency():
             t[n, j, rng.integers(2, 24), rng.integers(2, 16)] = 1.0
     acc, avg, cnt, _ = pose_ref.pck_accuracy(t.copy(), t)
     assert avg == 1.0 and cnt == 17
+
+
+def test_g9_gaussian_targets_restatement_matches_reference(golden_dir):
+    """oracle.pose_ref.gaussian_targets vs the reference's JointsDataset.generate_target
+    (data/JointsDataset.py:230-286) on the G9 fixture (inside / border / outside / invisible joints)."""
+    import numpy as np
+    from oracle import pose_ref
+    g = np.load(os.path.join(golden_dir, "g9_targets.npz"))
+    for tag in ("s2", "s3"):
+        sigma, wh, hh, wi, hi = g[f"{tag}_cfg"]
+        for b in range(g[f"{tag}_joints"].shape[0]):
+            t, w = pose_ref.gaussian_targets(g[f"{tag}_joints"][b, :, :2], g[f"{tag}_vis"][b, :, 0], (int(wh), int(hh)), (int(wi), int(hi)), float(sigma))
+            assert np.array_equal(w, g[f"{tag}_tw"][b])
+            assert np.array_equal(t, g[f"{tag}_target"][b])
