@@ -86,3 +86,33 @@ def test_trainer_plateau_scheduler_and_sgd(tmp_path):
     ck = torch.load(os.path.join(exp, "models", "checkpoint_epoch_final.pth"), weights_only=False)
     assert "momentum_buffer" in ck["optimizer_state_dict"]["state"][0]
     assert ck["scheduler_state_dict"]["mode"] == "max"      # the reference steps ReduceLROnPlateau(mode="max") on the loss
+
+
+def test_evaluator_end_to_end_on_synthetic_loader():
+    """03_evaluate.py counterpart: flip-test forward, device decode, rescoring + OKS-NMS, AP.  With the
+    ground truth built from the model's own detections the AP must be 1."""
+    from stlpose_amd import PoseHighResolutionNet
+    from stlpose_amd.evaluate import Evaluator, oks_ap
+    B, H, W = 4, 96, 64
+    torch.manual_seed(6)
+    model = PoseHighResolutionNet("tiny", "fp32").cuda()
+    batches = _loader(3, B, H, W, 8)
+    loader = []
+    for i, (img, tgt, tw, _) in enumerate(batches):
+        meta = {"center": torch.tensor([[W / 2.0, H / 2.0]] * B), "scale": torch.tensor([[W / 200.0, H / 200.0]] * B),
+                "score": torch.ones(B), "image_id": torch.arange(i * B, (i + 1) * B), "image": [f"im{j}.jpg" for j in range(B)]}
+        loader.append((img, tgt, tw, meta))
+    ev = Evaluator(model)
+    out = ev.evaluate_model(loader)
+    assert np.isfinite(out["loss"]) and 0.0 <= out["accuracy"] <= 1.0 and out["stats"] is None
+    assert len(out["results"]) == 3 * B and all(len(r["keypoints"]) == 51 for r in out["results"])
+    gts = []
+    for n, r in enumerate(out["results"]):
+        k = np.array(r["keypoints"]).reshape(17, 3)
+        k[:, 2] = 2
+        gts.append(dict(id=n + 1, image_id=r["image_id"], category_id=1, keypoints=k.reshape(-1).tolist(), num_keypoints=17,
+                        area=float(W * H), bbox=[0, 0, W, H], iscrowd=0))
+    stats = oks_ap(gts, out["results"])
+    assert np.isclose(stats[0], 1.0) and np.isclose(stats[5], 1.0)
+    out2 = ev.evaluate_model(loader, gt_annotations=gts)
+    assert np.allclose(out2["stats"][[0, 5]], 1.0)
