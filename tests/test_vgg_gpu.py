@@ -31,3 +31,22 @@ def test_vgg_cpu_fails_loudly():
     m = VGGPerceptualLoss(resize=False, state_dict=vgg_ref.synth_vgg_weights())
     with pytest.raises(RuntimeError, match="no CPU path"):
         m(torch.rand(1, 3, 16, 16), torch.rand(1, 3, 16, 16))
+
+
+def test_offline_perceptual_loss_dict(tmp_path):
+    """the JSON the reference's load_perceptual_loss_dict reads (lib/loss.py:153-198):
+    file name, {image name: float}, one value per (styled, original) pair = the oracle's loss of that pair."""
+    import json
+    from stlpose_amd.perceptual_offline import create_offline_perceptual_loss, dict_filename
+    w = vgg_ref.synth_vgg_weights()
+    g = torch.Generator().manual_seed(5)
+    pairs = [(f"{i:012d}.jpg", torch.rand(3, 64, 48, generator=g), torch.rand(3, 64, 48, generator=g)) for i in range(3)]
+    vgg = VGGPerceptualLoss(resize=True, state_dict=w, compute_dtype="fp32").cuda()
+    d = create_offline_perceptual_loss(pairs, vgg, str(tmp_path), alpha=0.5, styles="all")
+    path = tmp_path / dict_filename(0.5, "all")
+    assert path.name == "perceptual_loss_dict_alpha_0.5_styles_all.json" and path.exists()
+    loaded = json.loads(open(path).read())
+    assert loaded == d and set(d) == {p[0] for p in pairs}
+    for name, a, b in pairs:
+        ref = vgg_ref.vgg_perceptual_loss(a[None], b[None], w, resize=True).item()
+        assert abs(d[name] - ref) <= 1e-3 * abs(ref)
