@@ -107,6 +107,14 @@ __device__ __forceinline__ void mma16<float>(f32x4& acc, const V16& a, const V16
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w[s]), __uint_as_float(b.w[s]), acc, 0, 0, 0);
 }
 
+// 1/sqrt(x) in fp32: hardware estimate + one Newton step (full fp32 accuracy, ~6 instructions; the
+// fp64 sqrt + divide it replaces costs ~60 in every kernel prologue).  The variance itself is still
+// formed in fp64 (sum of squares minus squared mean cancels).
+__device__ __forceinline__ float rsqrt_nr(float x) {
+    const float r = __frsqrt_rn(x);
+    return r * (1.5f - 0.5f * x * r * r);
+}
+
 // ---------------------------------------------------------------- per-channel constants of an stl_src
 // ca/cb/cc: v = ca*x + cb (BN) or v = ca*dt + cb*y + cc (BNBWD).  mu/rs: mean and 1/std (for yhat).
 __device__ __forceinline__ void bn_mean_rstd(const stl_src& s, int c, int C, float& mean, float& rstd) {
@@ -121,10 +129,10 @@ __device__ __forceinline__ void bn_mean_rstd(const stl_src& s, int c, int C, flo
         double var = s1 * (double)s.inv_count - m * m;
         if (var < 0.0) var = 0.0;
         mean = (float)m;
-        rstd = (float)(1.0 / sqrt(var + (double)s.eps));
+        rstd = rsqrt_nr((float)(var + (double)s.eps));
     } else {
         mean = s.rmean[c];
-        rstd = (float)(1.0 / sqrt((double)s.rvar[c] + (double)s.eps));
+        rstd = rsqrt_nr(s.rvar[c] + s.eps);
     }
 }
 
@@ -186,10 +194,10 @@ __device__ __forceinline__ void bn_raw_finish(const stl_src& s, const SrcRaw& r,
         double var = s1 * (double)s.inv_count - m * m;
         if (var < 0.0) var = 0.0;
         mean = (float)m;
-        rstd = (float)(1.0 / sqrt(var + (double)s.eps));
+        rstd = rsqrt_nr((float)(var + (double)s.eps));
     } else {
         mean = r.rm;
-        rstd = (float)(1.0 / sqrt((double)r.rv + (double)s.eps));
+        rstd = rsqrt_nr(r.rv + s.eps);
     }
 }
 __device__ __forceinline__ void src_raw_load(const stl_src& s, int c, int C, SrcRaw& r) {

@@ -431,7 +431,7 @@ class Engine:
                 wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = x.B, x.H, x.W, x.C, y.H, y.W, y.C
                 wg.ks, wg.stride = kks, kstride
                 ctile = capi.lib().stl_wgrad_chunk(C.byref(wg))   # 32, or 64 for the wide-channel variant
-                big = (self.esz == 2 and kstride == 1 and os.environ.get("STLPOSE_WGRAD_TILE", "256") == "256"
+                big = (self.esz == 2 and kstride == 1 and os.environ.get("STLPOSE_WGRAD_TILE", "128") == "256"
                        and x.B * y.H * y.W >= 256 * 64 and (ctile == 32 or kks == 1))
                 if big:   # 256-pixel tiles: fewer barriers per pixel, but one block per CU
                     wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32, maxpx=256,
