@@ -480,7 +480,7 @@ Plan choose_plan(const stl_conv& p, int ck) {
         const bool c32 = !getenv("STL_CONV_NO_C32_SHAPE4") && p.Co <= 32 && p.stride == 1 && p.ks == 3;
         if (shape == 4 && !c32) continue;
         if (c32 && shape != 4) continue;
-        // kernel family: measured on MI355X (tools/conv_probe2.py) the wave-specialised kernel wins for
+        // kernel family: measured on MI355X (tools/conv_probe6.py; end to end the threshold Co >= 256 is the better one) the wave-specialised kernel wins for
         // stride-2 convs and for the small, deep maps (Co >= 256), the uniform kernel elsewhere
         const int ws_minco = getenv("STL_CONV_WS_MINCO") ? atoi(getenv("STL_CONV_WS_MINCO")) : 256;
         const int want_ws = getenv("STL_CONV_WS") ? atoi(getenv("STL_CONV_WS"))
