@@ -22,7 +22,7 @@ def _stale(target: str, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    hdrs = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "conv_common.inc"), os.path.join(CSRC, "conv_ws.inc"),
+    hdrs = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "conv_common.inc"), os.path.join(CSRC, "conv_ws.inc"), os.path.join(CSRC, "conv1x1.inc"),
             os.path.join(HERE, "..", "include", "stlpose_hip.h")]
     objs, jobs = [], []
     for s in SOURCES:

@@ -16,6 +16,7 @@
 //   all per-vector index arithmetic is hoisted out of the stage loop.
 //   LDS strides (96 B per pixel, taps*64+32 B per filter row) are conflict-free for ds_read_b128.
 #include <stdlib.h>
+#include <cstring>
 #include "common.cuh"
 
 namespace {
@@ -371,6 +372,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 }
 
 #include "conv_ws.inc"
+#include "conv1x1.inc"
 
 template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, int OCC = 1>
 int launch(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
@@ -583,6 +585,9 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     STL_CHECK(!(p.out_stats && p.red), "conv: out_stats and red are exclusive");
     STL_CHECK(!p.red || p.mask_y, "conv: red needs mask_y");
     STL_CHECK(!p.mask_y || (p.mask_bn.gamma && p.mask_bn.beta && (p.mask_bn.stats || (p.mask_bn.rmean && p.mask_bn.rvar))), "conv: mask BN incomplete");
+
+    if (use_1x1(p))  // wide 1x1 convolutions: streaming GEMM kernel (conv1x1.inc)
+        return p.dtype == STL_BF16 ? run_1x1<__bf16>(p, (hipStream_t)stream) : run_1x1<float>(p, (hipStream_t)stream);
 
     // block shape and pixel tile: planned once by stl_conv_plan (shape >= 0), else searched here
     Plan plan;

@@ -65,6 +65,8 @@ CONV_CASES = [
     (2, 16, 12, 48, 48, 3, 1),     # ragged channel chunk (W48 widths)
     (1, 30, 22, 128, 32, 3, 1),    # odd tile edges
     (2, 13, 11, 32, 32, 3, 2),     # odd input size, stride 2
+    (2, 12, 9, 96, 192, 1, 1),     # streaming 1x1 kernel, ragged K stage / channel block (W48 widths)
+    (3, 11, 7, 192, 96, 1, 1),     # streaming 1x1 kernel, pixel count not a multiple of the tile
 ]
 
 
