@@ -4,7 +4,7 @@ f = glob.glob(sys.argv[1] + "/*/*counter_collection.csv")[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"]
-    if not any(t in k for t in ("conv_core", "conv_ws", "wgrad")): continue
+    if not any(t in k for t in ("conv_core", "conv_ws", "wgrad", "conv1x1")): continue
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
     if r["Counter_Name"] == "SQ_WAVES": n[k] += 1
 for k, c in agg.items():
