@@ -7,11 +7,11 @@ KB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads -> doubl
 
 usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <n_launches> <out.json>
 """
-import csv, glob, json, sys
+import csv, glob, json, os, sys
 
 
 def last_wgrads(d, counter, n):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = max(glob.glob(d + "/*/*counter_collection.csv"), key=os.path.getmtime)
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and "wgrad_kernel" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     rows = rows[-n:]

@@ -1,6 +1,6 @@
 import csv, sys, glob, collections, re
 d = sys.argv[1]; nsteps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
-f = glob.glob(d + '/*/*kernel_trace.csv')[0]
+import os; f = max(glob.glob(d + '/*/*kernel_trace.csv'), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 def short(n):
     m = re.search(r'conv_core_kernelI(\w+?)Li(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)', n)
