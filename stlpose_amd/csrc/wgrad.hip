@@ -585,11 +585,16 @@ int dispatch64(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
 
 // channel tile (64 or 32) of the kernel variant stl_conv_wgrad picks for this problem
 int wgrad_chunk(const stl_wgrad& p) {
-    // opt-in (STL_WGRAD_64=1): on MI355X the wide variant halves the activation re-reads but, at HRNet's
-    // sizes, loses as much again to the 4x larger split-K slabs (23.5 vs 23.7 ms/step, slower in isolation)
+    // Default: 1x1 convolutions only ("k1").  There the wide variant halves the re-reads of the 113 MB
+    // layer1 tensors and its slabs are small (21.8 vs 22.0 ms/step); for 3x3 it loses as much again to
+    // the 4x larger split-K slabs (STL_WGRAD_64=all enables it there, STL_WGRAD_64=0 disables it).
     const char* e = getenv("STL_WGRAD_64");
-    if (!e) return 32;
-    if (e[0] == 'k' && p.ks != 1) return 32;  // "k1": 1x1 convolutions only
+    if (e && e[0] == '0') return 32;
+    if ((!e || e[0] == 'k') && p.ks != 1) {
+        // ... except 3x3 layers with very many pixels per weight (layer1.conv2 at 96x72): slabs are small there too
+        const int64_t minpx = getenv("STL_WGRAD_64_MINPX") ? atoll(getenv("STL_WGRAD_64_MINPX")) : (int64_t)1 << 62;
+        if ((int64_t)p.B * p.Ho * p.Wo < minpx) return 32;
+    }
     return (p.dtype == STL_BF16 && p.stride == 1 && p.Co >= 64 && p.Ci >= 64) ? 64 : 32;
 }
 

@@ -431,7 +431,10 @@ class Engine:
                 wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = x.B, x.H, x.W, x.C, y.H, y.W, y.C
                 wg.ks, wg.stride = kks, kstride
                 ctile = capi.lib().stl_wgrad_chunk(C.byref(wg))   # 32, or 64 for the wide-channel variant
-                big = (self.esz == 2 and kstride == 1 and os.environ.get("STLPOSE_WGRAD_TILE", "128") == "256"
+                want256 = os.environ.get("STLPOSE_WGRAD_TILE", "128") == "256"
+                if ctile == 64 and kks == 1:
+                    want256 = os.environ.get("STLPOSE_WGRAD_K1_TILE", "128") == "256"
+                big = (self.esz == 2 and kstride == 1 and want256
                        and x.B * y.H * y.W >= 256 * 64 and (ctile == 32 or kks == 1))
                 if big:   # 256-pixel tiles: fewer barriers per pixel, but one block per CU
                     wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32, maxpx=256,
@@ -446,7 +449,7 @@ class Engine:
                 # launch; 256 keeps the launch itself fastest.)
                 budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS", "256"))
                 if ctile == 64:
-                    budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS64", "128"))
+                    budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS64", "512"))
                 elif kks == 1 and self.esz == 2:
                     budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS_K1", str(budget)))
                 top = max(1, min(npt, budget // chunks if chunks <= budget else 1))

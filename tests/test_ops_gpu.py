@@ -121,7 +121,9 @@ def test_conv_bn_relu_chain_forward_backward(case, dt, wtile, monkeypatch):
         wtile = int(wtile[4:])
         if dt != "bf16" or s != 1 or Ci < 64 or Co < 64:
             pytest.skip("the wide variant is bf16, stride 1, Co and Ci >= 64")
-        monkeypatch.setenv("STL_WGRAD_64", "1")
+        monkeypatch.setenv("STL_WGRAD_64", "all")
+    else:
+        monkeypatch.setenv("STL_WGRAD_64", "0")
     if wtile == 256 and (dt != "bf16" or s != 1):
         pytest.skip("256-pixel weight-gradient tiles are bf16, stride 1 only")
     g = torch.Generator(device="cuda").manual_seed(2)
