@@ -801,7 +801,11 @@ extern "C" int stl_fuse_backward(const stl_fuse_bwd* pp, void* stream) {
     for (int t = 0; t < p.nbn; ++t) STL_CHECK(p.bn[t].x && p.bn[t].stats && p.rstats[t], "fuse_bwd: bn term %d incomplete", t);
     const int bd = stat_block(p.C);
     const size_t total = (size_t)p.B * p.H * p.W * (p.C / 8);
-    int nb = nblocks_for(total, bd, getenv("STL_FUSE_BLOCKS") ? atoi(getenv("STL_FUSE_BLOCKS")) : 256);
+    // grid: 256 blocks measured best end to end for the branch tensors (fewer statistics atomics, less
+    // contention with co-running kernels); the 113 MB layer1 tensors need more loads in flight
+    int cap = (int)(total / (size_t)(bd * 16));
+    cap = cap < 256 ? 256 : (cap > 1024 ? 1024 : cap);
+    int nb = nblocks_for(total, bd, getenv("STL_FUSE_BLOCKS") ? atoi(getenv("STL_FUSE_BLOCKS")) : cap);
     const size_t lds = (size_t)(p.nbn > 0 ? p.nbn : 1) * 2 * p.C * 4 + (size_t)bd * 2 * 8 * 4;
     if (p.dtype == STL_BF16)
         hipLaunchKernelGGL(fuse_bwd_kernel<__bf16>, dim3(nb), dim3(bd), lds, ST, p);
@@ -818,7 +822,11 @@ extern "C" int stl_upsample_backward(const stl_upbwd* pp, void* stream) {
     STL_CHECK(p.du && p.dt && p.bn.x && p.bn.stats && p.rstats, "upsample_bwd: null pointer");
     const int bd = stat_block(p.C);
     const size_t total = (size_t)p.B * p.H * p.W * (p.C / 8);
-    int nb = nblocks_for(total, bd, getenv("STL_FUSE_BLOCKS") ? atoi(getenv("STL_FUSE_BLOCKS")) : 256);
+    // grid: 256 blocks measured best end to end for the branch tensors (fewer statistics atomics, less
+    // contention with co-running kernels); the 113 MB layer1 tensors need more loads in flight
+    int cap = (int)(total / (size_t)(bd * 16));
+    cap = cap < 256 ? 256 : (cap > 1024 ? 1024 : cap);
+    int nb = nblocks_for(total, bd, getenv("STL_FUSE_BLOCKS") ? atoi(getenv("STL_FUSE_BLOCKS")) : cap);
     const size_t lds = (size_t)2 * p.C * 4 + (size_t)bd * 2 * 8 * 4;
     if (p.dtype == STL_BF16)
         hipLaunchKernelGGL(upsample_bwd_kernel<__bf16>, dim3(nb), dim3(bd), lds, ST, p);
