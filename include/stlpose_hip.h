@@ -188,6 +188,10 @@ typedef struct stl_wprep { /* one conv weight: OIHW fp32 master -> kernel layout
 } stl_wprep;
 int stl_weight_prep(int dtype, const float* master, void* wk, const stl_wprep* tab, int n,
                     int nblocks, void* stream);
+/* The same over a sub-range of the table: `tab` points at the first entry of the range, blk_base is
+ * that entry's blk0.  Used per gradient bucket, right after the bucket's optimiser slice. */
+int stl_weight_prep_range(int dtype, const float* master, void* wk, const stl_wprep* tab, int n,
+                          int blk_base, int nblocks, void* stream);
 
 typedef struct stl_slab { /* one wgrad result: sum partial[s] -> grad (OIHW fp32) */
     int64_t part_off; /* element offset into `partials`; a multiple of 4 (16-byte aligned) when Ci % 4 == 0 */
@@ -218,6 +222,14 @@ int stl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const
                   int32_t* step, void* stream);
 int stl_sgd_step(float* p, const float* g, float* mom, int64_t n, const float* hyper, int32_t* step,
                  void* stream);
+/* Per-bucket form: stl_optim_begin_step increments `step` once, the *_slice calls then update any
+ * contiguous slices of the flat buffers (pointers already offset) with that step count -- the
+ * optimiser of a gradient bucket runs as soon as the bucket is final, overlapped with backward. */
+int stl_optim_begin_step(int32_t* step, void* stream);
+int stl_adam_slice(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                   const int32_t* step, void* stream);
+int stl_sgd_slice(float* p, const float* g, float* mom, int64_t n, const float* hyper, const int32_t* step,
+                  void* stream);
 
 /* VGG perceptual path (reference lib/loss.py:17-58). */
 int stl_maxpool2x2(int dtype, const void* x, void* out, int B, int H, int W, int C, void* stream);

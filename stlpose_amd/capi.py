@@ -120,6 +120,10 @@ SIGNATURES = {
     "stl_flip_merge": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "stl_final_preds": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "stl_weight_prep": [i32, vp, vp, vp, i32, i32, vp],
+    "stl_weight_prep_range": [i32, vp, vp, vp, i32, i32, i32, vp],
+    "stl_optim_begin_step": [vp, vp],
+    "stl_adam_slice": [vp, vp, vp, vp, i64, vp, vp, vp],
+    "stl_sgd_slice": [vp, vp, vp, i64, vp, vp, vp],
     "stl_reduce_slabs": [vp, vp, vp, i32, i32, vp],
     "stl_reduce_slabs_range": [C.POINTER(ReduceRange), vp],
     "stl_bn_running_update": [vp, vp, vp, vp, i32, f32, vp],

@@ -467,12 +467,13 @@ __device__ __forceinline__ int find_entry(const int* blk0_first, int stride_ints
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void weight_prep_kernel(const float* master, T* wk, const stl_wprep* tab, int n) {
-    const int ei = find_entry(&tab[0].blk0, sizeof(stl_wprep) / 4, n, blockIdx.x);
+__global__ __launch_bounds__(256) void weight_prep_kernel(const float* master, T* wk, const stl_wprep* tab, int n, int blk_base) {
+    const int bx = blockIdx.x + blk_base;  // tab points at the first entry of the range, blk0 values are table-absolute
+    const int ei = find_entry(&tab[0].blk0, sizeof(stl_wprep) / 4, n, bx);
     const stl_wprep e = tab[ei];
     const int t = e.ks * e.ks;
     const int64_t tot = (int64_t)e.Co * e.Ci * t;
-    const int64_t base = (int64_t)(blockIdx.x - e.blk0) * 1024;
+    const int64_t base = (int64_t)(bx - e.blk0) * 1024;
     for (int r = 0; r < 4; ++r) {
         const int64_t i = base + r * 256 + threadIdx.x;
         if (i >= tot) return;
@@ -930,10 +931,22 @@ extern "C" int stl_flip_merge(const float* a, const float* bflip, float* out, co
 extern "C" int stl_weight_prep(int dtype, const float* master, void* wk, const stl_wprep* tab, int n, int nblocks, void* stream) {
     if (n == 0) return 0;
     if (dtype == STL_BF16)
-        hipLaunchKernelGGL(weight_prep_kernel<__bf16>, dim3(nblocks), dim3(256), 0, ST, master, (__bf16*)wk, tab, n);
+        hipLaunchKernelGGL(weight_prep_kernel<__bf16>, dim3(nblocks), dim3(256), 0, ST, master, (__bf16*)wk, tab, n, 0);
     else
-        hipLaunchKernelGGL(weight_prep_kernel<float>, dim3(nblocks), dim3(256), 0, ST, master, (float*)wk, tab, n);
+        hipLaunchKernelGGL(weight_prep_kernel<float>, dim3(nblocks), dim3(256), 0, ST, master, (float*)wk, tab, n, 0);
     STL_LAUNCH_CHECK("weight_prep");
+    return 0;
+}
+
+extern "C" int stl_weight_prep_range(int dtype, const float* master, void* wk, const stl_wprep* tab, int n, int blk_base, int nblocks,
+                                     void* stream) {
+    if (n == 0 || nblocks == 0) return 0;
+    STL_CHECK(master && wk && tab && n > 0 && blk_base >= 0 && nblocks > 0, "weight_prep_range: bad arguments");
+    if (dtype == STL_BF16)
+        hipLaunchKernelGGL(weight_prep_kernel<__bf16>, dim3(nblocks), dim3(256), 0, ST, master, (__bf16*)wk, tab, n, blk_base);
+    else
+        hipLaunchKernelGGL(weight_prep_kernel<float>, dim3(nblocks), dim3(256), 0, ST, master, (float*)wk, tab, n, blk_base);
+    STL_LAUNCH_CHECK("weight_prep_range");
     return 0;
 }
 
@@ -978,6 +991,26 @@ extern "C" int stl_sgd_step(float* p, const float* g, float* mom, int64_t n, con
     hipLaunchKernelGGL(inc_step_kernel, dim3(1), dim3(1), 0, ST, step);
     hipLaunchKernelGGL(sgd_kernel, dim3(nblocks_for((size_t)n, 256, 4096)), dim3(256), 0, ST, p, g, mom, n, hyper, step);
     STL_LAUNCH_CHECK("sgd_step");
+    return 0;
+}
+
+extern "C" int stl_optim_begin_step(int32_t* step, void* stream) {
+    hipLaunchKernelGGL(inc_step_kernel, dim3(1), dim3(1), 0, ST, step);
+    STL_LAUNCH_CHECK("optim_begin_step");
+    return 0;
+}
+
+extern "C" int stl_adam_slice(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, const int32_t* step, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(adam_kernel, dim3(nblocks_for((size_t)n, 256, 4096)), dim3(256), 0, ST, p, g, m, v, n, hyper, step);
+    STL_LAUNCH_CHECK("adam_slice");
+    return 0;
+}
+
+extern "C" int stl_sgd_slice(float* p, const float* g, float* mom, int64_t n, const float* hyper, const int32_t* step, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(sgd_kernel, dim3(nblocks_for((size_t)n, 256, 4096)), dim3(256), 0, ST, p, g, mom, n, hyper, step);
+    STL_LAUNCH_CHECK("sgd_slice");
     return 0;
 }
 

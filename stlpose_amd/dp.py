@@ -47,6 +47,12 @@ class FlatAllReduce:
             w.wait()
         self._works = []
 
+    def reduce_bucket(self, i: int, force: bool = False):
+        """All-reduce bucket i now and make the CURRENT stream wait for it (stream-ordered for RCCL)."""
+        if self.world == 1 and not force:
+            return
+        dist.all_reduce(self.buckets[i], op=dist.ReduceOp.SUM, group=self.pg, async_op=True).wait()
+
     def all_reduce(self):
         self.launch()
         self.wait()

@@ -313,8 +313,10 @@ class Engine:
             e.Co, e.Ci, e.ks, e.Cip, e.patch, e.blk0 = c.Co, c.Ci, c.ks, c.Cik, int(c.patch), blk
             blk += math.ceil(c.Co * c.Ci * c.ks * c.ks / 1024)
         self._wprep_blocks = blk
+        self._wprep_blk0 = [tab[i].blk0 for i in range(len(self.convs))] + [blk]
         self._wprep_tab = _to_device(tab, self.dev)
         self._wprep_n = len(self.convs)
+        self.weights_ready = False   # set by a caller that has already run prep_weights_range for every bucket
 
     # ------------------------------------------------------------------ backward program
     def _new_grad(self, a: Act) -> torch.Tensor:
@@ -620,9 +622,26 @@ class Engine:
         capi.call("stl_weight_prep", self.dtype, st.master.data_ptr(), self.wk.data_ptr(), self._wprep_tab.data_ptr(),
                   self._wprep_n, self._wprep_blocks, stream)
 
+    def prep_weights_range(self, i: int, stream: int):
+        """weights -> kernel layout for the convolutions whose parameters lie in gradient bucket i."""
+        b = self.buckets[i]
+        if "conv0" not in b:
+            import bisect
+            offs = [c.master_off for c in self.convs]          # forward order == ascending offset
+            assert offs == sorted(offs)
+            b["conv0"], b["conv1"] = bisect.bisect_left(offs, b["lo"]), bisect.bisect_left(offs, b["hi"])
+        i0, i1 = b["conv0"], b["conv1"]
+        if i1 > i0:
+            st = self.store
+            capi.call("stl_weight_prep_range", self.dtype, st.master.data_ptr(), self.wk.data_ptr(),
+                      self._wprep_tab.data_ptr() + i0 * C.sizeof(capi.WPrep), i1 - i0, self._wprep_blk0[i0],
+                      self._wprep_blk0[i1] - self._wprep_blk0[i0], stream)
+
     def forward(self, stream: int, update_running: bool = True):
         """weights -> kernel layout, zero statistics, forward program, running-stat update."""
-        self.prep_weights(stream)
+        if not self.weights_ready:
+            self.prep_weights(stream)
+        self.weights_ready = False
         if self.training:
             self.stats.zero_()
         self._run(self.fwd_ops, stream)

@@ -171,6 +171,7 @@ class Trainer:
         sd = ck["model_state_dict"] if "model_state_dict" in ck else ck
         sd = {(k[len(_PREFIX):] if k.startswith(_PREFIX) else k): v for k, v in sd.items()}
         self.model.load_state_dict(sd)   # in place: the parameters are views of the flat master buffer
+        self.ts.invalidate_weights()
         if only_model:
             return
         self._load_optimizer_state_dict(ck["optimizer_state_dict"])

@@ -70,12 +70,14 @@ def test_sgd_nesterov_step_runs():
     assert np.isfinite(l) and l < l0
 
 
-def test_gradient_buckets_cover_the_flat_buffer_and_dp_path_matches(monkeypatch):
+@pytest.mark.parametrize("bucket_optim", ["0", "1"])
+def test_gradient_buckets_cover_the_flat_buffer_and_dp_path_matches(monkeypatch, bucket_optim):
     """The backward program reduces the weight-gradient slabs bucket by bucket (no serial tail) and
     records an event per bucket; the data-parallel path all-reduces each bucket on a communication
     stream as soon as that event fires.  With ONE rank (RCCL all-reduce = identity) the bucketed path
     must give exactly the gradients and losses of the plain path."""
     import torch.distributed as dist
+    monkeypatch.setenv("STLPOSE_BUCKET_OPTIM", bucket_optim)   # "1": optimiser + weight layouts per bucket as well
     torch.manual_seed(5)
     img, tgt, tw = _batch(4, 256, 192, seed=7)
 
