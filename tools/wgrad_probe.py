@@ -44,7 +44,11 @@ def run(B, H, W, Ci, Co, ks, maxpx, splits, gq=True):
             st = " stamps(us): " + " ".join(f"{(v[i] - v[0]) / 100.0:.1f}" for i in range(1, 9))
         print(f"{B}x{H}x{W} Ci{Ci} Co{Co} k{ks} tile {wg.TH}x{wg.TW} npt {npt} nsplit {ns:4d} blocks {ns*chunks:4d} tiles/blk {math.ceil(npt/ns):3d}  {us:7.1f} us{st}", flush=True)
 
-for maxpx in (128, 256):
+if __name__ == "__main__" and len(sys.argv) > 1:
+    a = [int(v) for v in sys.argv[1].split(",")]
+    run(a[0], a[1], a[2], a[3], a[4], a[5], a[7], [a[6]])
+    sys.exit(0)
+for maxpx in ((128, 256) if __name__ == "__main__" else ()):
     run(32, 96, 72, 32, 32, 3, maxpx, [64, 128, 256, 384, 512])
     run(32, 48, 36, 64, 64, 3, maxpx, [16, 32, 64, 96, 128])
     run(32, 24, 18, 128, 128, 3, maxpx, [4, 8, 16, 24, 32])
