@@ -16,6 +16,7 @@
 //   all per-vector index arithmetic is hoisted out of the stage loop.
 //   LDS strides (96 B per pixel, taps*64+32 B per filter row) are conflict-free for ds_read_b128.
 #include <stdlib.h>
+#include <algorithm>
 #include <cstring>
 #include "common.cuh"
 
@@ -624,11 +625,14 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     int gx = ceil_div(k.npt, 8) * 8;
     // resident waves per SIMD ~2: persistent blocks that loop over their tiles with the next tile's
     // loads in flight beat a second round of fresh blocks (measured: tools/conv_probe7.py)
+    k.ny = ceil_div(p.Co, sh.co);
+    // The budget is for the whole grid (pixel blocks x channel blocks): one resident round of blocks
+    // (256 for the 8-wave shapes, 1024 for the 4-wave ones); with ny channel blocks per pixel tile the
+    // pixel dimension gets budget / ny (3x3 32->256 at 96x72: 102 -> 90 us; tools/conv_probe8.py)
     int cap = sh.ws ? 256 : (sh.thr == 512 ? 256 : 1024);
-    if (const char* e = getenv("STL_CONV_CAP512")) cap = sh.ws ? 256 : (sh.thr == 512 ? atoi(e) : 1024);
+    if (!getenv("STL_CONV_CAP_PER_TILE")) cap = std::max(8, (cap / k.ny + 7) / 8 * 8);
     if (const char* e = getenv("STL_CONV_GRID_CAP")) cap = atoi(e) > 0 ? (atoi(e) + 7) / 8 * 8 : cap;
     if (gx > cap) gx = cap;
-    k.ny = ceil_div(p.Co, sh.co);
     dim3 grid(gx * k.ny, 1);
     const int nva = ceil_div(k.HP * 4, sh.lthr);
     if (getenv("STL_CONV_DEBUG"))
