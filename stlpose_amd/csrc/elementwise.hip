@@ -57,20 +57,28 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(const stl_fuse p) {
         cs[(t * 2) * C + c] = a, cs[(t * 2 + 1) * C + c] = b;
     }
     __syncthreads();
-    const size_t total = (size_t)p.B * p.H * p.W * VPC;
-    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (size_t)gridDim.x * blockDim.x) {
-        const size_t pi = v / VPC;
-        const int cg = (int)(v - pi * VPC), c0 = cg * 8;
-        const int x = (int)(pi % p.W);
-        const size_t by = pi / p.W;
-        const int y = (int)(by % p.H), b = (int)(by / p.H);
+    // 32-bit index math (tensors hold < 2^31 elements, checked on the host); sums whose terms all have
+    // the output's resolution (every residual block end) need no pixel coordinates at all
+    const uint32_t total = (uint32_t)p.B * p.H * p.W * VPC;
+    bool flat = true;
+    for (int t = 0; t < p.nterms; ++t) flat = flat && p.t[t].shift == 0;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
+        const uint32_t pi = v / (uint32_t)VPC;
+        const int c0 = (int)(v - pi * VPC) * 8;
+        int x = 0, y = 0, b = 0;
+        if (!flat) {
+            const uint32_t by = pi / (uint32_t)p.W;
+            x = (int)(pi - by * p.W);
+            b = (int)(by / (uint32_t)p.H);
+            y = (int)(by - (uint32_t)b * p.H);
+        }
         float s[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] = 0.f;
         for (int t = 0; t < p.nterms; ++t) {
             const stl_term& tm = p.t[t];
             const int hs = p.H >> tm.shift, ws = p.W >> tm.shift;
-            const size_t off = (((size_t)b * hs + (y >> tm.shift)) * ws + (x >> tm.shift)) * C + c0;
+            const size_t off = flat ? (size_t)v * 8 : (((size_t)b * hs + (y >> tm.shift)) * ws + (x >> tm.shift)) * C + c0;
             float f[8];
             load8<T>(tm.src.x, off, f);
             if (tm.src.mode == STL_SRC_BN) {
@@ -88,7 +96,7 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(const stl_fuse p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) s[j] = fmaxf(s[j], 0.f);
         }
-        store8<T>(p.out, pi * C + c0, s);
+        store8<T>(p.out, (size_t)v * 8, s);
     }
 }
 
@@ -780,6 +788,7 @@ extern "C" int stl_fuse_forward(const stl_fuse* pp, void* stream) {
                   "fuse: %dx%d not divisible by 2^%d", p.H, p.W, p.t[t].shift);
     }
     const size_t total = (size_t)p.B * p.H * p.W * (p.C / 8);
+    STL_CHECK(total * 8 < (1ull << 31), "fuse: tensors of 2^31 or more elements are not supported");
     const size_t lds = (size_t)p.nterms * 2 * p.C * 4;
     if (p.dtype == STL_BF16)
         hipLaunchKernelGGL(fuse_fwd_kernel<__bf16>, dim3(nblocks_for(total, 256, getenv("STL_FUSEF_BLOCKS") ? atoi(getenv("STL_FUSEF_BLOCKS")) : 2048)), dim3(256), lds, ST, p);
