@@ -418,7 +418,7 @@ int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStrea
             if (nva <= 3) return launch<T, KS, 4, 2, 4, 4, 3, Q>(k, grid, lds, st);
             break;
         case 4:
-            if (nva <= 3) return launch<T, KS, 4, 1, 2, 2, 3, Q, 4>(k, grid, lds, st);
+            if (nva <= 3) return launch<T, KS, 4, 1, 2, 2, 3, Q, (Q ? 3 : 4)>(k, grid, lds, st);
             if (nva <= 6) return launch<T, KS, 4, 1, 2, 2, 6, Q, 3>(k, grid, lds, st);
             break;
         case 5:
