@@ -143,12 +143,16 @@ __global__ void fuse_bwd_kernel(const stl_fuse_bwd p) {
         if (p.nbn > 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[0][j] += d[j];
-            for (int t = 0; t < p.nbn; ++t) {
-                float y[8];
-                load8<T>(p.bn[t].x, off, y);
+            // fully unrolled with static indices: a runtime index into acc[][] would put it in scratch memory
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    acc[1 + t][j] += d[j] * (y[j] - mu[(t * 2) * C + c0 + j]) * mu[(t * 2 + 1) * C + c0 + j];
+            for (int t = 0; t < 4; ++t) {
+                if (t < p.nbn) {
+                    float y[8];
+                    load8<T>(p.bn[t].x, off, y);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        acc[1 + t][j] += d[j] * (y[j] - mu[(t * 2) * C + c0 + j]) * mu[(t * 2 + 1) * C + c0 + j];
+                }
             }
         }
     }
@@ -156,15 +160,17 @@ __global__ void fuse_bwd_kernel(const stl_fuse_bwd p) {
         // sets: for each term t: r1 (set 0) -> rstats[t] slot 0 ; r2 (set 1+t) -> rstats[t] slot 1
         double* dst[5];
         int which[5];
-        float(*sel)[8] = acc;
         // first flush r2 sets + one r1; r1 is shared by all terms, so add it to each term's buffer
-        for (int t = 0; t < p.nbn; ++t) {
-            dst[0] = p.rstats[t], which[0] = 0;
-            dst[1] = p.rstats[t], which[1] = 1;
-            float two[2][8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) two[0][j] = sel[0][j], two[1][j] = sel[1 + t][j];
-            flush_sets<2>(two, red, C, VPC, dst, which, 2);
+        for (int t = 0; t < 4; ++t) {
+            if (t < p.nbn) {
+                dst[0] = p.rstats[t], which[0] = 0;
+                dst[1] = p.rstats[t], which[1] = 1;
+                float two[2][8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) two[0][j] = acc[0][j], two[1][j] = acc[1 + t][j];
+                flush_sets<2>(two, red, C, VPC, dst, which, 2);
+            }
         }
     }
 }
