@@ -480,7 +480,8 @@ Plan choose_plan(const stl_conv& p, int ck) {
         if ((shape == 1 || shape == 5) && p.Co > 32) continue;
         if (shape == 3) continue;  // 256x128 block spills registers; reachable via STL_CONV_SHAPE only
         // 128 px x 32 co blocks (four per CU) win in isolation for the C<=32 3x3 layers (21.7 vs 28.2 us)
-        const bool c32 = !getenv("STL_CONV_NO_C32_SHAPE4") && p.Co <= 32 && p.stride == 1 && p.ks == 3;
+        const int s4_maxco = getenv("STL_CONV_SHAPE4_MAXCO") ? atoi(getenv("STL_CONV_SHAPE4_MAXCO")) : 32;
+        const bool c32 = !getenv("STL_CONV_NO_C32_SHAPE4") && p.Co <= s4_maxco && p.stride == 1 && p.ks == 3;
         if (shape == 4 && !c32) continue;
         if (c32 && shape != 4) continue;
         // kernel family: measured on MI355X (tools/conv_probe6.py; end to end the threshold Co >= 256 is the better one) the wave-specialised kernel wins for
