@@ -74,7 +74,10 @@ __device__ __forceinline__ void store4(void* base, size_t elem, const float* f) 
 
 // WM x WN waves, MT pixel tiles and NTW channel tiles per wave; NVA staging vectors per thread for
 // the input halo; Q: source is BNBWD (second tensor on load).
-template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, int OCC>
+// WR: 1 = the filters are known to be LDS-resident (whole K in one chunk): the per-stage filter
+// staging registers and descriptors do not exist in that instantiation (no spills at 128 VGPRs);
+// -1 = decided at run time (k.wres)
+template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, int OCC, int WR>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const ConvK k) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTHR = 64 * WM * WN;
@@ -91,6 +94,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     const int bl = blockIdx.x >> 3;
     const int by = bl % k.ny, lx = bl / k.ny;
     const int n0 = by * BCO;
+    const bool wres = WR < 0 ? (k.wres != 0) : (WR == 1);
 
     STAMP(0);
     if (k.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[12] = __builtin_amdgcn_s_memtime();
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
             ra[i] = ldg16((const char*)p.src.x + (size_t)off * sizeof(T));
             if (Q) rq[i] = ldg16((const char*)p.src.y + (size_t)off * sizeof(T));
         }
-        if (!k.wres) {
+        if (!wres) {
 #pragma unroll
             for (int i = 0; i < NVB; ++i) {
                 const bool ok = en && b_g[i] >= 0 && (k0 + ((tid + i * NTHR) & 3) * KV) < p.Ci;
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
             const int v = tid + i * NTHR;
             *reinterpret_cast<V16*>(sA + (v >> 2) * PSA + (v & 3) * 16) = val;
         }
-        if (!k.wres) {
+        if (!wres) {
 #pragma unroll
             for (int i = 0; i < NVB; ++i) {
                 const bool ok = b_g[i] >= 0 && (k0 + ((tid + i * NTHR) & 3) * KV) < p.Ci;
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
         }
     };
 
-    if (k.wres) {  // whole K fits one chunk: filters stay resident in LDS for all tiles (rb[] is free then)
+    if (wres) {  // whole K fits one chunk: filters stay resident in LDS for all tiles (rb[] is free then)
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
             const bool ok = b_g[i] >= 0 && (((tid + i * NTHR) & 3) * KV) < p.Ci;
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     STAMP(3);
     if (have) tile_setup(t, a_go);
     issue(a_go, 0, have);
-    if (k.wres) {
+    if (wres) {
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
             const bool ok = b_g[i] >= 0 && (((tid + i * NTHR) & 3) * KV) < p.Ci;
@@ -375,15 +379,15 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 #include "conv_ws.inc"
 #include "conv1x1.inc"
 
-template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, int OCC = 1>
+template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, int OCC = 1, int WR = -1>
 int launch(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, OCC>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, OCC, WR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, OCC>), grid, dim3(64 * WM * WN), lds, st, k);
+    hipLaunchKernelGGL((conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, OCC, WR>), grid, dim3(64 * WM * WN), lds, st, k);
     STL_LAUNCH_CHECK("conv_core");
     return 0;
 }
@@ -418,6 +422,7 @@ int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStrea
             if (nva <= 3) return launch<T, KS, 4, 2, 4, 4, 3, Q>(k, grid, lds, st);
             break;
         case 4:
+            if (nva <= 3 && k.wres) return launch<T, KS, 4, 1, 2, 2, 3, Q, 4, 1>(k, grid, lds, st);  // 113-123 VGPRs, no spills
             if (nva <= 3) return launch<T, KS, 4, 1, 2, 2, 3, Q, (Q ? 3 : 4)>(k, grid, lds, st);
             if (nva <= 6) return launch<T, KS, 4, 1, 2, 2, 6, Q, 3>(k, grid, lds, st);
             break;
