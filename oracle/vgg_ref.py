@@ -1,4 +1,5 @@
-"""ORACLE (test infrastructure, never imported by the product path).  PARITY UNPINNED.
+"""ORACLE (test infrastructure, never imported by the product path).  Pinned by fixture G10 except for
+torchvision's layer list (see below).
 
 Torch-ops restatement of ``VGGPerceptualLoss`` (reference ``src/lib/loss.py:17-58``).  The
 reference takes its convolution stack from ``torchvision.models.vgg16(pretrained=True)
@@ -6,9 +7,12 @@ reference takes its convolution stack from ``torchvision.models.vgg16(pretrained
 is absent from /root/reference and from this image, and whose weights need a download.  The
 layer layout below is torchvision's published VGG16 configuration "D":
 conv64,conv64,M,conv128,conv128,M,conv256x3,M,conv512x3 (all 3x3 pad 1 with bias, ReLU after
-each conv, 2x2/2 max-pool), sliced [0:4],[4:9],[9:16],[16:23] as at loss.py:28-31.  No
-reference run or fixture exists for it, so it is checked only against itself with synthetic
-weights.
+each conv, 2x2/2 max-pool), sliced [0:4],[4:9],[9:16],[16:23] as at loss.py:28-31.
+``tests/golden/make_golden.py g10`` runs the reference's OWN VGGPerceptualLoss class on that layer
+list (plain torch.nn layers standing in for the absent torchvision, synthetic weights below) and
+``tests/test_oracle_golden.py`` checks this restatement against it: the reference's slicing, channel
+repeat, normalisation, bilinear resize and L1 lines are pinned; the third-party layer list and the
+ImageNet weights are not (parity unpinned for those two only).
 """
 from __future__ import annotations
 

@@ -1069,7 +1069,7 @@ extern "C" int stl_gaussian_targets(const float* joints_xy, const float* vis, fl
 }
 
 extern "C" int stl_maxpool2x2(int dtype, const void* x, void* out, int B, int H, int W, int C, void* stream) {
-    STL_CHECK(C % 8 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool: C%%8 / even H,W required");
+    STL_CHECK(C % 8 == 0 && H >= 2 && W >= 2, "maxpool: C%%8 == 0 and H, W >= 2 required");  // odd H/W: floor, like nn.MaxPool2d
     const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
     if (dtype == STL_BF16)
         hipLaunchKernelGGL(maxpool_kernel<__bf16>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, x, out, B, H, W, C);

@@ -150,6 +150,7 @@ class Engine:
         self._keep: List = []  # keep ctypes structs / tensors alive
         self._progs: Dict[int, Tuple] = {}
         self.act_bytes = 0
+        self.generation = 0   # forward passes seen by the autograd bridge (hrnet._Fn stale-backward check)
         # static I/O
         self.img = torch.zeros(B, 3, H, W, dtype=torch.float32, device=self.dev)
         self.out: Optional[torch.Tensor] = None

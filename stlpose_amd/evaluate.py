@@ -206,31 +206,75 @@ def oks_ap(gt_annotations: Sequence[dict], results: Sequence[dict], img_ids: Opt
 
 
 # ---------------------------------------------------------------------------------------------- driver
+def gather_eval_shards(process_group, seq: np.ndarray, preds: np.ndarray, boxes: np.ndarray, image_ids: Sequence[int],
+                       sums: Sequence[float]):
+    """Data-parallel evaluation (replaces the DataParallel gather of 03_evaluate.py:100,176-188):
+    every rank has run the network on its shard of the validation batches; all-gather the few KB per batch the
+    host-side scoring needs -- ``preds (n,17,3)``, ``boxes (n,6)``, ``image_ids``, plus the loss / PCK sums --
+    and restore the loader's order (``seq`` = (global batch index, position in batch) per person) so that
+    OKS-NMS and AP see exactly what a single process would have seen."""
+    import torch.distributed as dist
+    payload = (np.asarray(seq, np.int64).reshape(-1, 2), preds, boxes, [int(v) for v in image_ids], [float(v) for v in sums])
+    world = dist.get_world_size(process_group)
+    parts = [None] * world
+    dist.all_gather_object(parts, payload, group=process_group)
+    seq = np.concatenate([p[0] for p in parts])
+    preds = np.concatenate([p[1] for p in parts])
+    boxes = np.concatenate([p[2] for p in parts])
+    ids = np.concatenate([np.asarray(p[3], np.int64) for p in parts])
+    order = np.lexsort((seq[:, 1], seq[:, 0]))
+    sums = np.sum(np.asarray([p[4] for p in parts], np.float64), axis=0)
+    return preds[order], boxes[order], [int(v) for v in ids[order]], [float(v) for v in sums]
+
+
 class Evaluator:
     """03_evaluate.py:114-216 on the HIP path.  ``evaluate_model`` returns a dict with the mean
-    loss, mean PCK, the COCO result list and (when ground truth is given) the 10 AP/AR numbers."""
+    loss, mean PCK, the COCO result list and (when ground truth is given) the 10 AP/AR numbers.
 
-    def __init__(self, model, device="cuda", model_name: str = "HRNet", flip: bool = True):
+    With ``process_group`` (one process per GPU) rank r evaluates batches r, r + world, ... of the loader
+    (``shard_loader=True``; pass False when the loader is already sharded by a DistributedSampler and give
+    each batch's global index in ``metadata['batch_index']``), the per-person results are all-gathered
+    (``gather_eval_shards``) and every rank scores the full set; only rank 0 writes ``preds_file``."""
+
+    def __init__(self, model, device="cuda", model_name: str = "HRNet", flip: bool = True, process_group=None,
+                 shard_loader: bool = True):
         from .loss import PersonMSELoss
         self.model, self.device, self.model_name, self.flip = model, torch.device(device), model_name, flip
         self.loss_function = PersonMSELoss()
+        self.pg, self.shard_loader = process_group, shard_loader
+        self.rank, self.world = 0, 1
+        if process_group is not None:
+            import torch.distributed as dist
+            self.rank, self.world = dist.get_rank(process_group), dist.get_world_size(process_group)
+
+    def _batch_outputs(self, imgs, target, target_weight, centers, scales):
+        """network + loss + PCK + decode for one batch (the only device work of the evaluation):
+        returns (loss, avg PCK, keypoints (n,17,2) in image coordinates, max_vals (n,17,1))."""
+        from .inference import forward_pass
+        from .pose_parsing import accuracy, get_final_preds_hrnet
+        imgs = imgs.float().to(self.device)
+        target = target.float().to(self.device)
+        output = forward_pass(model=self.model, img=imgs, model_name=self.model_name, device=self.device, flip=self.flip)
+        loss = float(self.loss_function(output, target, target_weight.float().to(self.device)).item())
+        keypoints, max_vals, _ = get_final_preds_hrnet(heatmaps=output, center=centers, scale=scales)
+        return loss, float(accuracy(output, target)[1]), keypoints, max_vals
 
     @torch.no_grad()
     def evaluate_model(self, loader: Iterable, gt_annotations: Optional[Sequence[dict]] = None, labels_file: Optional[str] = None,
                        preds_file: Optional[str] = None) -> dict:
-        from .inference import forward_pass
-        from .pose_parsing import accuracy, get_final_preds_hrnet
-        self.model.eval()
-        losses, accs, all_preds, all_boxes, image_ids = [], [], [], [], []
-        for imgs, target, target_weight, metadata in loader:
-            imgs = imgs.float().to(self.device)
-            target = target.float().to(self.device)
-            output = forward_pass(model=self.model, img=imgs, model_name=self.model_name, device=self.device, flip=self.flip)
-            losses.append(self.loss_function(output, target, target_weight.float().to(self.device)).clone())
-            accs.append(accuracy(output, target)[1])
+        if self.model is not None:
+            self.model.eval()
+        loss_sum = acc_sum = 0.0
+        nb = 0
+        all_preds, all_boxes, image_ids, seq = [], [], [], []
+        for bi, (imgs, target, target_weight, metadata) in enumerate(loader):
+            if self.world > 1 and self.shard_loader and bi % self.world != self.rank:
+                continue
+            gbi = bi if (self.world == 1 or self.shard_loader) else int(metadata.get("batch_index", bi * self.world + self.rank))
             centers, scales = np.asarray(metadata["center"], np.float64), np.asarray(metadata["scale"], np.float64)
             score = np.asarray(metadata["score"], np.float64)
-            keypoints, max_vals, _ = get_final_preds_hrnet(heatmaps=output, center=centers, scale=scales)
+            loss, acc, keypoints, max_vals = self._batch_outputs(imgs, target, target_weight, centers, scales)
+            loss_sum, acc_sum, nb = loss_sum + loss, acc_sum + acc, nb + 1
             n = keypoints.shape[0]
             preds = np.zeros((n, keypoints.shape[1], 3), np.float32)
             preds[:, :, :2], preds[:, :, 2:3] = keypoints[:, :, :2], max_vals
@@ -239,13 +283,21 @@ class Evaluator:
             boxes[:, 4], boxes[:, 5] = np.prod(scales * 200, 1), score
             all_preds.append(preds), all_boxes.append(boxes)
             image_ids += [int(v) for v in np.asarray(metadata["image_id"]).tolist()]
-        results = rescore_and_nms(np.concatenate(all_preds), np.concatenate(all_boxes), image_ids) if all_preds else []
-        if preds_file:
+            seq += [(gbi, i) for i in range(n)]
+        preds = np.concatenate(all_preds) if all_preds else np.zeros((0, 17, 3), np.float32)
+        boxes = np.concatenate(all_boxes) if all_boxes else np.zeros((0, 6))
+        sums = [loss_sum, acc_sum, float(nb)]
+        if self.world > 1:
+            preds, boxes, image_ids, sums = gather_eval_shards(self.pg, np.asarray(seq, np.int64).reshape(-1, 2), preds, boxes,
+                                                               image_ids, sums)
+        results = rescore_and_nms(preds, boxes, image_ids) if len(preds) else []
+        if preds_file and self.rank == 0:
             with open(preds_file, "w") as f:
                 json.dump(results, f)
         if gt_annotations is None and labels_file is not None:
             with open(labels_file) as f:
                 gt_annotations = json.load(f)["annotations"]
         stats = oks_ap(gt_annotations, results, img_ids=sorted(set(image_ids))) if gt_annotations is not None else None
-        return dict(loss=float(torch.stack(losses).mean().item()) if losses else float("nan"),
-                    accuracy=float(np.mean(accs)) if accs else 0.0, results=results, stats=stats)
+        nbt = sums[2]
+        return dict(loss=sums[0] / nbt if nbt else float("nan"), accuracy=sums[1] / nbt if nbt else 0.0,
+                    results=results, stats=stats)

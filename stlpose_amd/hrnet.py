@@ -46,6 +46,15 @@ def _dtype_code(name: str) -> int:
     raise ValueError(f"compute_dtype must be 'bf16' or 'fp32', got {name!r}")
 
 
+def norm_device(device) -> torch.device:
+    """``torch.device('cuda') != torch.device('cuda:0')``: always carry the index, so that a store
+    created for 'cuda' is recognised when an input tensor reports 'cuda:0'."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 class _Fn(torch.autograd.Function):
     """Autograd bridge: the whole network is one node; its backward replays the HIP backward plan
     and deposits parameter gradients straight into the flat gradient buffer."""
@@ -55,11 +64,22 @@ class _Fn(torch.autograd.Function):
         ctx.net, ctx.eng = net, eng
         eng.img.copy_(img)
         eng.forward(torch.cuda.current_stream().cuda_stream)
+        # The activations backward needs live in the engine's planned buffers, not in ctx: a later
+        # forward through the same plan overwrites them.  Remember which forward this node belongs to.
+        eng.generation += 1
+        ctx.generation = eng.generation
         return eng.out.clone()
 
     @staticmethod
     def backward(ctx, gout):
         net, eng = ctx.net, ctx.eng
+        if ctx.generation != eng.generation:
+            raise RuntimeError(
+                "stlpose_amd.PoseHighResolutionNet: backward through a stale forward -- the plan for this "
+                f"(batch, resolution, mode) ran forward #{eng.generation} after the forward (#{ctx.generation}) being "
+                "differentiated, and its activations were overwritten (the reference's autograd keeps one set "
+                "per call; this engine keeps one per plan).  Call backward before the next forward of the same "
+                "shape, or concatenate the inputs into one batch.")
         eng.dout.copy_(gout)
         eng.backward(torch.cuda.current_stream().cuda_stream)
         net._publish_grads()
@@ -117,7 +137,7 @@ class PoseHighResolutionNet(nn.Module):
 
     def _packed(self, device) -> bool:
         st = self._store
-        if st is None or st.device != device:
+        if st is None or st.device != norm_device(device):
             return False
         first, last = self._reg.params[0][0], self._reg.params[-1][0]
         return (self._tensor(first).data_ptr() == st.master.data_ptr()
@@ -125,6 +145,12 @@ class PoseHighResolutionNet(nn.Module):
 
     def _pack(self, device):
         """(Re)point every parameter/buffer at its slice of the flat fp32 storage on `device`."""
+        if getattr(self, "_pinned_by", None) is not None:
+            raise RuntimeError(
+                "stlpose_amd.PoseHighResolutionNet: the flat parameter storage is held by a TrainStep / Trainer "
+                f"on {self._store.device}; re-packing it for {device} would silently detach the optimiser from the "
+                "module's parameters.  Keep the model on the TrainStep's device (or build a new TrainStep).")
+        device = norm_device(device)
         st = ParamStore(self._reg, device)
         with torch.no_grad():
             for key, shape in self._reg.params:

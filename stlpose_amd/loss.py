@@ -64,3 +64,25 @@ def apply_perceptual_loss(exp_data, params, loss, perceptual_loss):
     if exp_data["training"]["perceptual_weight"] == "add":
         return loss + loss * mean_perc
     raise SystemExit(f"ERROR! Weighting method '{exp_data['training']['perceptual_weight']}' is not supported")
+
+
+def perceptual_affine(exp_data, params, perceptual_loss):
+    """The same decision tree as ``apply_perceptual_loss`` (reference lib/loss.py:97-150) expressed as
+    ``loss -> scale * loss + offset`` with host floats, for the fused train step (the scale multiplies
+    dL/dout inside the loss kernel): returns (scale, offset)."""
+    tr = exp_data["training"]
+    if "perceptual_loss" not in tr:
+        tr["perceptual_loss"] = False
+    use = bool(getattr(params, "use_perceptual_loss", False) or tr["perceptual_loss"])
+    if exp_data["dataset"]["dataset_name"] != "styled_coco" or not use:
+        return 1.0, 0.0
+    if perceptual_loss is None:
+        raise KeyError("perceptual loss enabled but the batch metadata has no 'perceptual_loss' entry")
+    mean_perc = float(torch.as_tensor(perceptual_loss).float().mean())
+    if tr.get("lambda_D") is not None and tr.get("lambda_P") is not None:
+        return float(tr["lambda_D"]), float(tr["lambda_P"]) * mean_perc
+    if "perceptual_weight" not in tr:
+        tr["perceptual_weight"] = "add"
+    if tr["perceptual_weight"] == "add":
+        return 1.0 + mean_perc, 0.0
+    raise SystemExit(f"ERROR! Weighting method '{tr['perceptual_weight']}' is not supported")

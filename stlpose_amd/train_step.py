@@ -27,10 +27,13 @@ class TrainStep:
                  momentum: float = 0.9, nesterov: bool = False, process_group=None, bucket_mb: float = 32.0,
                  use_graph: bool = True, device=None):
         self.model = model
-        dev = torch.device(device or "cuda")
+        from .hrnet import norm_device
+        dev = norm_device(device or "cuda")
         if not model._packed(dev):
             model.to(dev)
             model._pack(dev)
+        import weakref
+        model._pinned_by = weakref.ref(self)   # forward() must never re-pack under us (it would orphan store/optimiser state)
         model.train()
         self.dev = dev
         self.store = model._store
@@ -63,10 +66,24 @@ class TrainStep:
         self.use_graph = use_graph
         self._g_fb: Optional[torch.cuda.CUDAGraph] = None
         self._g_opt: Optional[torch.cuda.CUDAGraph] = None
+        self._loss_scale, self._loss_offset = 1.0, 0.0
+        # graph mode + process group: bucket events recorded at capture time are not re-recorded by a
+        # replay, so the overlapped per-bucket all-reduce has nothing to wait on -- run eagerly instead
+        if self.use_graph and process_group is not None:
+            self.use_graph = False
 
     # ------------------------------------------------------------------ pieces
     def set_lr(self, lr: float):
         self.hyper[0] = lr
+
+    def set_loss_affine(self, scale: float = 1.0, offset: float = 0.0):
+        """loss <- scale * MSE + offset for the NEXT step(s): the scalar re-weighting of the reference's
+        ``apply_perceptual_loss`` (lib/loss.py:97-150; 'add': scale = 1 + mean(p); lambda form: scale =
+        lambda_D, offset = lambda_P * mean(p)).  The scale multiplies dL/dout inside the loss kernel."""
+        scale, offset = float(scale), float(offset)
+        if self.use_graph and self._g_fb is not None and (scale, offset) != (self._loss_scale, self._loss_offset):
+            self._g_fb = self._g_opt = None   # the scale is a kernel argument baked into the capture
+        self._loss_scale, self._loss_offset = scale, offset
 
     def load_batch(self, img: torch.Tensor, target: torch.Tensor, target_weight: torch.Tensor):
         self.eng.img.copy_(img, non_blocking=True)
@@ -86,7 +103,10 @@ class TrainStep:
         e.forward(st)
         B, J = e.out.shape[:2]
         capi.call("stl_mse_loss", e.out.data_ptr(), self.target.data_ptr(), self.tweight.data_ptr(), e.dout.data_ptr(),
-                  self._partial.data_ptr(), self._nblk, self.loss.data_ptr(), B, J, e.out[0, 0].numel(), 1.0, st)
+                  self._partial.data_ptr(), self._nblk, self.loss.data_ptr(), B, J, e.out[0, 0].numel(),
+                  self._loss_scale, st)
+        if self._loss_scale != 1.0 or self._loss_offset != 0.0:   # the kernel scales only dL/dout
+            self.loss.mul_(self._loss_scale).add_(self._loss_offset)
         e.backward(st)
 
     def _optim(self):

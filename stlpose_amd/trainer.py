@@ -29,9 +29,9 @@ from typing import Iterable, Optional
 import numpy as np
 import torch
 
-from .hrnet import PoseHighResolutionNet
+from .hrnet import PoseHighResolutionNet, norm_device
 from .inference import forward_pass
-from .loss import PersonMSELoss
+from .loss import PersonMSELoss, perceptual_affine
 from .pose_parsing import accuracy
 from .train_step import TrainStep
 
@@ -75,7 +75,12 @@ class Trainer:
         self.batch_size = int(batch_size)
         self.arch, self.compute_dtype = arch, compute_dtype
         self.checkpoint, self.resume_training = checkpoint, resume_training
-        self.pg, self.device = process_group, torch.device(device)
+        self.pg, self.device = process_group, norm_device(device)
+        self.rank, self.world = 0, 1
+        if process_group is not None:
+            import torch.distributed as dist
+            self.rank, self.world = dist.get_rank(process_group), dist.get_world_size(process_group)
+        self.params = None   # optional argparse-like object with .use_perceptual_loss (02_train.py:208-212)
         self.acc_every = max(1, int(acc_every))   # PCK needs the heatmaps on the host (metrics.accuracy): every n-th batch
         tr = exp_data["training"]
         self.num_epochs = int(tr["num_epochs"])
@@ -86,7 +91,8 @@ class Trainer:
         self.iterations, self.cur_epoch = 0, 0
         h, w = exp_data["dataset"]["image_size"]
         self.image_size = (int(h), int(w))
-        os.makedirs(os.path.join(exp_path, "models"), exist_ok=True)
+        if self.rank == 0:
+            os.makedirs(os.path.join(exp_path, "models"), exist_ok=True)
 
     # ------------------------------------------------------------------ model / optimiser / scheduler
     def setup_model(self):
@@ -111,6 +117,37 @@ class Trainer:
             self.scheduler = None
         if self.checkpoint is not None:
             self.load_checkpoint(self.checkpoint, only_model=not self.resume_training)
+        self._broadcast_state()
+
+    # ------------------------------------------------------------------ one process per GPU
+    def _broadcast_state(self):
+        """Replicas must start from rank 0's weights / BatchNorm buffers / optimiser state (DataParallel
+        re-broadcasts module state every step, 02_train.py:109; here once is enough because every rank then
+        applies the same all-reduced gradients)."""
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        st, ts = self.ts.store, self.ts
+        for t in (st.master, st.bufs, st.nbt, ts.m, ts.v, ts.step_count, ts.hyper):
+            if t is not None:
+                dist.broadcast(t, src=dist.get_global_rank(self.pg, 0), group=self.pg)
+        self.ts.invalidate_weights()
+
+    def _mean_over_ranks(self, *vals):
+        """Loaders are sharded, so per-rank epoch statistics differ: average them so that every rank logs
+        and -- more importantly -- feeds ReduceLROnPlateau the same number (replicas would otherwise drift
+        apart in learning rate)."""
+        if self.world == 1:
+            return vals
+        import torch.distributed as dist
+        t = torch.tensor(vals, dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+        return tuple((t / self.world).tolist())
+
+    def _barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier(group=self.pg)
 
     @property
     def lr(self) -> float:
@@ -136,11 +173,11 @@ class Trainer:
             group.update(betas=(hyper[1], hyper[2]), eps=hyper[3], weight_decay=hyper[4], amsgrad=False)
         else:
             group.update(momentum=hyper[5], dampening=0, weight_decay=hyper[4], nesterov=bool(hyper[6]))
-        return {"state": state, "param_groups": [group]}
+        return {"state": state, "param_groups": [group], "stl_step": step}
 
     def _load_optimizer_state_dict(self, sd: dict) -> None:
         st, ts = self.ts.store, self.ts
-        step = 0
+        step, have_momentum = 0, False
         for i, (k, shape) in enumerate(st.reg.params):
             s = sd["state"].get(i)
             if s is None:
@@ -153,17 +190,27 @@ class Trainer:
                 step = int(float(s["step"]))
             else:
                 ts.m[a:a + n].copy_(s["momentum_buffer"].reshape(-1))
+                have_momentum = True
+        if have_momentum:
+            # torch.optim.SGD keeps no step counter; the fused kernel treats step <= 1 as "no momentum
+            # buffer yet" (b = g).  With a buffer loaded the next step must be a continuation, like torch's.
+            step = max(step, int(sd.get("stl_step", 1)), 1)
         ts.step_count.fill_(step)
         lr = float(sd["param_groups"][0]["lr"])
         self._shadow.param_groups[0]["lr"] = lr
         ts.set_lr(lr)
 
     def save_checkpoint(self, epoch: int, finished: bool = False) -> str:
+        """rank 0 writes (every rank holds identical weights); the others wait at the barrier."""
         name = "checkpoint_epoch_final.pth" if finished else f"checkpoint_epoch_{epoch}.pth"
         path = os.path.join(self.exp_path, "models", name)
+        if self.rank != 0:
+            self._barrier()
+            return path
         msd = {_PREFIX + k: v.detach().cpu() for k, v in self.model.state_dict().items()}
         torch.save({"epoch": epoch, "model_state_dict": msd, "optimizer_state_dict": self._optimizer_state_dict(),
                     "scheduler_state_dict": self.scheduler.state_dict() if self.scheduler is not None else {}}, path)
+        self._barrier()
         return path
 
     def load_checkpoint(self, path: str, only_model: bool = False) -> None:
@@ -181,20 +228,25 @@ class Trainer:
 
     # ------------------------------------------------------------------ epochs
     def training_loop(self):
-        if self.checkpoint is None or not self.resume_training:
+        if self.rank != 0:
+            self.training_logs = None
+        elif self.checkpoint is None or not self.resume_training:
             self.training_logs = create_train_logs(self.exp_path)
         else:
             self.training_logs = load_train_logs(self.exp_path)
         for epoch in range(self.cur_epoch, self.num_epochs):
             self.validation_epoch(epoch)
             self.train_epoch(epoch)
+            self.train_loss, self.valid_loss, self.train_acc, self.valid_acc = self._mean_over_ranks(
+                self.train_loss, self.valid_loss, self.train_acc, self.valid_acc)
             if self.scheduler_type == "plateau":
                 self.scheduler.step(self.valid_loss)
             elif self.scheduler_type == "step":
                 self.scheduler.step()
             self.ts.set_lr(self.lr)
-            update_train_logs(self.exp_path, self.training_logs, self.iterations, self.train_loss, self.valid_loss,
-                              self.train_acc, self.valid_acc)
+            if self.rank == 0:
+                update_train_logs(self.exp_path, self.training_logs, self.iterations, self.train_loss, self.valid_loss,
+                                  self.train_acc, self.valid_acc)
             if epoch % self.save_frequency == 0:
                 self.save_checkpoint(epoch)
         self.save_checkpoint(self.num_epochs, finished=True)
@@ -202,9 +254,13 @@ class Trainer:
     def train_epoch(self, epoch: int):
         self.model.train()
         losses, accs = [], []
-        for i, (imgs, target, target_weight, _meta) in enumerate(self.train_loader):
+        for i, (imgs, target, target_weight, meta) in enumerate(self.train_loader):
             self.ts.load_batch(imgs.float().to(self.device, non_blocking=True), target.float().to(self.device, non_blocking=True),
                                target_weight.float().to(self.device, non_blocking=True))
+            # 02_train.py:208-212: loss = apply_perceptual_loss(exp_data, params, loss, metadata["perceptual_loss"]).
+            # It is an affine map of the MSE by per-batch host scalars, so it becomes (scale, offset) of the fused step.
+            perc = meta.get("perceptual_loss") if isinstance(meta, dict) else None
+            self.ts.set_loss_affine(*perceptual_affine(self.exp_data, self.params, perc))
             loss = self.ts.step()
             self.iterations += 1
             losses.append(loss.clone())            # stays on the device: no host sync per iteration

@@ -14,7 +14,9 @@ back-propagated through in-tree).
 The reference takes the weights from ``torchvision.models.vgg16(pretrained=True)`` (a download);
 here they come from a state_dict with the reference module's own key names
 (``blocks.<slice>.<features index>.{weight,bias}``) or torchvision's (``features.<index>.*``).
-PARITY UNPINNED: no reference run / fixture exists for this path.
+Parity: fixture G10 (tests/golden/g10_vgg.npz) is the reference's own ``VGGPerceptualLoss`` run on a
+torchvision-free VGG16-D layer list with synthetic weights -- its slicing, channel repeat, normalisation,
+resize and L1 lines are pinned; torchvision's layer list itself (third party, absent) stays restated.
 """
 from __future__ import annotations
 
@@ -164,8 +166,8 @@ class VGGPerceptualLoss(nn.Module):
             r = torch.empty(B2, 3, 224, 224, device=dev)
             capi.call("stl_bilinear_nchw", x.data_ptr(), r.data_ptr(), B2, 3, H, W, 224, 224, st)
             x, H, W = r, 224, 224
-        if H % 8 or W % 8:
-            raise RuntimeError(f"VGGPerceptualLoss(resize=False) needs H, W divisible by 8, got {H}x{W}")
+        if H < 8 or W < 8:   # three 2x2 max-pools (floor, like nn.MaxPool2d) must leave at least one pixel
+            raise RuntimeError(f"VGGPerceptualLoss needs H, W >= 8, got {H}x{W}")
         key = (B2, H, W)
         plan = self._plans.get(key)
         if plan is None:

@@ -317,9 +317,166 @@ def gen_g9():
     print("G9 done")
 
 
+def gen_g8_train():
+    """G8b: HRNet-W48 TRAINING step from the reference (bs 2, 128x96): output sample, loss, the L2 norm of
+    every parameter gradient, a set of full gradients (the 48/96/192/384 widths exercise the ragged
+    channel-chunk paths of every kernel) and BatchNorm buffers after the step."""
+    tmp = tempfile.mkdtemp(prefix="stl_golden_")
+    if "CONFIG" not in sys.modules:
+        _install_shims(tmp)
+    from lib.loss import PersonMSELoss
+    m = _ref_model(tmp, "w48")
+    m.train()
+    img, tgt, tw = synth_batch(2, 128, 96, seed=48, sigma=2.0)
+    out = m(torch.from_numpy(img))
+    loss = PersonMSELoss()(out, torch.from_numpy(tgt), torch.from_numpy(tw))
+    loss.backward()
+    o = out.detach().numpy()
+    fx = dict(loss=np.float64(loss.item()), out_sample=o.reshape(-1)[::16].copy(), out_absmax=np.abs(o).max())
+    names = [k for k, _ in m.named_parameters()]
+    fx["param_keys"] = np.array(names)
+    fx["gradnorm_all"] = np.array([float(p_.grad.double().norm()) for _, p_ in m.named_parameters()])
+    nfull = 0
+    for k, p_ in m.named_parameters():
+        if any(re.fullmatch(pat, k) for pat in FULL_GRAD_KEYS) and p_.numel() <= 48 * 96 * 9:
+            fx["grad/" + k] = p_.grad.numpy().astype(np.float32)
+            nfull += 1
+    fx["buffernorm_all"] = np.array([float(v.double().norm()) for _, v in m.named_buffers()])
+    np.savez_compressed(os.path.join(HERE, "g8_w48_train.npz"), **fx)
+    print("G8b w48 train loss", loss.item(), "full grads", nfull)
+
+
+def gen_g10():
+    """G10: the reference's OWN ``VGGPerceptualLoss`` (lib/loss.py:17-58) -- its slicing, channel repeat,
+    ImageNet normalisation, bilinear resize and L1 lines run unchanged.  torchvision is absent here, so
+    ``torchvision.models.vgg16`` is a harness-side stand-in returning the published VGG16 "D" layer list
+    as plain torch.nn layers (the third-party part that stays restated), loaded with
+    oracle.vgg_ref.synth_vgg_weights() instead of the ImageNet download."""
+    from oracle import vgg_ref
+    tmp = tempfile.mkdtemp(prefix="stl_golden_")
+    if "CONFIG" not in sys.modules:
+        _install_shims(tmp)
+    import torch.nn as nn
+
+    def vgg16(pretrained=False, **kw):
+        cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
+        layers, cin = [], 3
+        for v in cfg:
+            if v == "M":
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        net = nn.Module()
+        net.features = nn.Sequential(*layers)
+        sd = vgg_ref.synth_vgg_weights()
+        own = net.state_dict()
+        own.update({k: v for k, v in sd.items() if k in own})
+        net.load_state_dict(own)
+        return net
+    tvm = types.ModuleType("torchvision.models")
+    tvm.vgg16 = vgg16
+    sys.modules["torchvision.models"] = tvm
+    sys.modules["torchvision"].models = tvm
+    import lib.loss as ref_loss
+    ref_loss.torchvision = sys.modules["torchvision"]
+    rng = np.random.Generator(np.random.PCG64(1010))
+    fx = {}
+    cases = [("rs_rgb", True, (2, 3, 40, 36)), ("rs_gray", True, (2, 1, 52, 44)), ("nr_rgb", False, (2, 3, 64, 48)),
+             ("nr_odd", False, (1, 3, 52, 44)), ("nr_gray", False, (2, 1, 32, 40))]
+    with torch.no_grad():
+        for tag, resize, shape in cases:
+            mod = ref_loss.VGGPerceptualLoss(resize=resize)
+            a = rng.random(shape).astype(np.float32)
+            b = np.clip(a + 0.25 * rng.standard_normal(shape).astype(np.float32), 0, 1)
+            l = mod(torch.from_numpy(a), torch.from_numpy(b))
+            fx[f"{tag}_in"], fx[f"{tag}_tg"], fx[f"{tag}_loss"], fx[f"{tag}_resize"] = a, b, np.float64(l.item()), np.int64(resize)
+            print("G10", tag, shape, "resize", resize, "loss", l.item())
+    np.savez_compressed(os.path.join(HERE, "g10_vgg.npz"), **fx)
+
+
+def gen_g12():
+    """G12: the reference's ``calc_dists`` / ``dist_acc`` (lib/metrics.py:268-318) and the box re-scoring
+    + OKS-NMS section of ``generate_submission_hrnet`` (:211-258).  lib/metrics.py imports pycocotools and
+    data.data_processing (absent / broken): both are empty harness-side module objects, the functions
+    called here do not touch them.  ``accuracy`` itself cannot run (line :355-356 indexes a 1-D array with a
+    4-tuple); acc/avg/cnt below are the reference's own get_max_preds_hrnet + calc_dists + dist_acc composed
+    by the loop of :353-362 with that line read as ``acc[i + 1] = dist_acc(dists[idx[i]])``."""
+    tmp = tempfile.mkdtemp(prefix="stl_golden_")
+    if "CONFIG" not in sys.modules:
+        _install_shims(tmp)
+    for name in ("pycocotools", "pycocotools.coco", "pycocotools.cocoeval", "data", "data.data_processing",
+                 "lib.utils", "lib.bounding_box"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["pycocotools.coco"].COCO = object
+    sys.modules["pycocotools.cocoeval"].COCOeval = object
+    captured = {}
+    sys.modules["data.data_processing"].convert_keypoints_to_coco_format = lambda kpts, f: captured.setdefault("kpts", kpts) and []
+    import lib.metrics as ref_metrics
+    from lib.pose_parsing import get_max_preds_hrnet
+    rng = np.random.Generator(np.random.PCG64(1212))
+    B, J, H, W = 6, 17, 24, 18
+    out = rng.standard_normal((B, J, H, W)).astype(np.float32)
+    tgt = np.zeros((B, J, H, W), np.float32)
+    for n in range(B):
+        for j in range(J):
+            y, x = rng.integers(0, H), rng.integers(0, W)
+            tgt[n, j, y, x] = 1.0
+            if (n + j) % 3 != 2:     # prediction near the target: a fixed cycle of offsets inside / outside the PCK radius
+                dy, dx = [(0, 0), (0, 1), (0, -1), (1, 0), (0, 2), (1, 1), (2, 3)][(3 * n + j) % 7]
+                out[n, j, np.clip(y + dy, 0, H - 1), np.clip(x + dx, 0, W - 1)] = 9.0
+    tgt[0, 0] = 0.0            # no target at all -> coordinates (0, 0) -> joint ignored (target <= 1)
+    tgt[:, 5] = 0.0            # a joint never annotated in the batch -> dist_acc returns -1
+    pred, _ = get_max_preds_hrnet(out)
+    tp, _ = get_max_preds_hrnet(tgt)
+    norm = np.ones((B, 2)) * np.array([H, W]) / 10
+    dists = ref_metrics.calc_dists(pred, tp, norm)
+    acc = np.zeros(J + 1)
+    avg, cnt = 0, 0
+    for i in range(J):
+        acc[i + 1] = ref_metrics.dist_acc(dists[i])
+        if acc[i + 1] >= 0:
+            avg, cnt = avg + acc[i + 1], cnt + 1
+    avg = avg / cnt if cnt != 0 else 0
+    if cnt != 0:
+        acc[0] = avg
+    fx = dict(output=out, target=tgt, dists=dists, acc=acc, avg_acc=np.float64(avg), cnt=np.int64(cnt), pred=pred)
+    # ---- re-scoring + OKS-NMS of generate_submission_hrnet on synthetic persons
+    n_img, per = 4, 5
+    kp = rng.random((n_img * per, 17, 3)) * np.array([200, 300, 1.0])
+    for i in range(n_img):           # near-duplicates inside an image so that NMS has something to drop
+        kp[i * per + 1] = kp[i * per] + rng.normal(0, 0.8, (17, 3)) * np.array([1, 1, 0])
+        kp[i * per + 3] = kp[i * per + 2] + rng.normal(0, 25.0, (17, 3)) * np.array([1, 1, 0])
+    kp[7, :, 2] = 0.05               # every joint below in_vis_thr -> valid_num == 0
+    boxes = np.zeros((n_img * per, 6))
+    boxes[:, 0:2] = rng.random((n_img * per, 2)) * 200
+    boxes[:, 2:4] = 0.5 + rng.random((n_img * per, 2))
+    boxes[:, 4] = 4000 + 2000 * rng.random(n_img * per)
+    boxes[:, 5] = rng.random(n_img * per)
+    ids = [1000 + i // per for i in range(n_img * per)]
+    import builtins, io
+    real_open = builtins.open
+    builtins.open = lambda *a, **k: io.StringIO() if (len(a) > 1 and "w" in a[1] and str(a[0]).endswith("g12_preds.json")) else real_open(*a, **k)
+    try:
+        ref_metrics.generate_submission_hrnet([kp.copy()], [boxes.copy()], list(ids), preds_file="g12_preds.json")
+    finally:
+        builtins.open = real_open
+    kept = captured["kpts"]
+    fx.update(sub_kpts=kp, sub_boxes=boxes, sub_ids=np.array(ids),
+              sub_kept_n=np.array([len(g) for g in kept]),
+              sub_kept_scores=np.concatenate([[p_["score"] for p_ in g] for g in kept]),
+              sub_kept_kpts=np.concatenate([np.stack([p_["keypoints"] for p_ in g]) for g in kept]),
+              sub_kept_img=np.concatenate([[p_["image"] for p_ in g] for g in kept]))
+    np.savez_compressed(os.path.join(HERE, "g12_metrics.npz"), **fx)
+    print("G12 avg_acc", avg, "cnt", cnt, "kept per image", [len(g) for g in kept])
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "g9":
-        gen_g9()
+    extra = dict(g9=gen_g9, g8train=gen_g8_train, g10=gen_g10, g12=gen_g12)
+    if len(sys.argv) > 1 and sys.argv[1] in extra:
+        extra[sys.argv[1]]()
     else:
         main()
-        gen_g9()
+        for fn in extra.values():
+            fn()

@@ -76,3 +76,82 @@ def test_rescore_and_nms_scores_and_format():
     assert all(r["image_id"] == 7 and r["category_id"] == 1 and len(r["keypoints"]) == 51 for r in res)
     scores = sorted(r["score"] for r in res)
     assert np.allclose(scores, sorted([0.5 * 0.9, 0.0, 0.8 * 0.5]), atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------- pinned by G12
+def test_rescoring_and_nms_match_reference_generate_submission(golden_dir):
+    """fixture G12: the reference's generate_submission_hrnet (lib/metrics.py:211-258) run on synthetic persons."""
+    g = np.load(os.path.join(golden_dir, "g12_metrics.npz"))
+    res = rescore_and_nms(g["sub_kpts"], g["sub_boxes"], g["sub_ids"].tolist())
+    per_img = {}
+    for r in res:
+        per_img.setdefault(r["image_id"], []).append(r)
+    assert [len(v) for v in per_img.values()] == g["sub_kept_n"].tolist()
+    assert [r["image_id"] for r in res] == g["sub_kept_img"].tolist()
+    np.testing.assert_allclose([r["score"] for r in res], g["sub_kept_scores"], rtol=1e-12)
+    np.testing.assert_allclose(np.array([r["keypoints"] for r in res]).reshape(-1, 17, 3), g["sub_kept_kpts"], rtol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------- sharded evaluation (gloo, world 2)
+def _fake_loader(nbatch=5, per=3):
+    rng = np.random.Generator(np.random.PCG64(5))
+    out = []
+    for b in range(nbatch):
+        n = per if b != nbatch - 1 else per - 1          # ragged last batch
+        meta = dict(center=rng.random((n, 2)) * 200, scale=0.5 + rng.random((n, 2)), score=rng.random(n),
+                    image_id=np.array([100 + (b * per + i) // 2 for i in range(n)]))
+        out.append((np.full((n, 1), b, np.float32), None, None, meta))
+    return out
+
+
+def _make_eval(pg):
+    from stlpose_amd.evaluate import Evaluator
+
+    class Fake(Evaluator):
+        def __init__(self, pg):
+            self.model, self.pg, self.shard_loader = None, pg, True
+            self.rank, self.world = 0, 1
+            if pg is not None:
+                import torch.distributed as dist
+                self.rank, self.world = dist.get_rank(pg), dist.get_world_size(pg)
+
+        def _batch_outputs(self, imgs, target, target_weight, centers, scales):
+            b = int(imgs[0, 0])
+            rng = np.random.Generator(np.random.PCG64(1000 + b))
+            n = len(centers)
+            kp = rng.random((n, 17, 2)) * 150 + centers[:, None, :]
+            if n > 1:
+                kp[1] = kp[0] + 0.5             # a near-duplicate for the NMS
+            return 0.1 * (b + 1), 0.05 * b, kp, rng.random((n, 17, 1))
+    return Fake(pg)
+
+
+def _eval_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = _make_eval(dist.group.WORLD).evaluate_model(_fake_loader())
+    q.put((rank, out["loss"], out["accuracy"], out["results"]))
+    dist.destroy_process_group()
+
+
+def test_sharded_evaluation_world2_equals_single_process():
+    import socket
+    import torch.multiprocessing as mp
+    ref = _make_eval(None).evaluate_model(_fake_loader())
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in range(2)), key=lambda t: t[0])
+    for p in ps:
+        p.join(60)
+    assert len(ref["results"]) > 0
+    for rank, loss, acc, results in got:
+        assert abs(loss - ref["loss"]) < 1e-12 and abs(acc - ref["accuracy"]) < 1e-12
+        assert results == ref["results"], f"rank {rank}: sharded results differ from the single-process run"

@@ -159,3 +159,40 @@ def test_g9_gaussian_targets_restatement_matches_reference(golden_dir):
             t, w = pose_ref.gaussian_targets(g[f"{tag}_joints"][b, :, :2], g[f"{tag}_vis"][b, :, 0], (int(wh), int(hh)), (int(wi), int(hi)), float(sigma))
             assert np.array_equal(w, g[f"{tag}_tw"][b])
             assert np.array_equal(t, g[f"{tag}_target"][b])
+
+
+def test_w48_train_step_oracle_vs_reference(golden_dir):
+    """G8b: W48 training step produced by the reference (ragged 48/96/192/384 widths)."""
+    from tests.golden.make_golden import synth_batch
+    g = _load(golden_dir, "g8_w48_train.npz")
+    img, tgt, tw = synth_batch(2, 128, 96, seed=48, sigma=2.0)
+    m = hrnet_ref.load_synth(hrnet_ref.RefPoseNet("w48")).train()
+    out = m(torch.from_numpy(img))
+    loss = pose_ref.person_mse_loss(out, torch.from_numpy(tgt), torch.from_numpy(tw))
+    loss.backward()
+    np.testing.assert_allclose(out.detach().numpy().reshape(-1)[::16], g["out_sample"], rtol=1e-4, atol=1e-5 * float(g["out_absmax"]))
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    norms = np.array([float(p.grad.double().norm()) for _, p in m.named_parameters()])
+    np.testing.assert_allclose(norms, g["gradnorm_all"], rtol=5e-4, atol=1e-7)
+
+
+def test_pck_oracle_vs_reference_calc_dists(golden_dir):
+    """G12: pose_ref.pck_accuracy against the reference's own calc_dists / dist_acc outputs."""
+    g = _load(golden_dir, "g12_metrics.npz")
+    acc, avg, cnt, pred = pose_ref.pck_accuracy(g["output"], g["target"])
+    np.testing.assert_allclose(acc, g["acc"], rtol=0, atol=1e-12)
+    assert abs(avg - float(g["avg_acc"])) < 1e-12 and cnt == int(g["cnt"]) and np.array_equal(pred, g["pred"])
+    assert 0.0 < avg < 1.0 and (g["acc"] == -1).any()
+
+
+def test_vgg_oracle_vs_reference_perceptual_loss(golden_dir):
+    """G10: the reference's own VGGPerceptualLoss (its slicing / repeat / normalise / resize / L1 lines) run on a
+    torchvision-free VGG16-D layer list with synthetic weights.  Pins oracle/vgg_ref.py."""
+    from oracle import vgg_ref
+    g = _load(golden_dir, "g10_vgg.npz")
+    w = vgg_ref.synth_vgg_weights()
+    for tag in ("rs_rgb", "rs_gray", "nr_rgb", "nr_odd", "nr_gray"):
+        with torch.no_grad():
+            l = vgg_ref.vgg_perceptual_loss(torch.from_numpy(g[f"{tag}_in"]), torch.from_numpy(g[f"{tag}_tg"]), w,
+                                            resize=bool(g[f"{tag}_resize"]))
+        assert abs(float(l) - float(g[f"{tag}_loss"])) <= 1e-5 * float(g[f"{tag}_loss"]), tag

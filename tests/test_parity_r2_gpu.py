@@ -1,0 +1,335 @@
+"""GPU parity at the configurations the throughput numbers are quoted on (round-2 additions).
+
+* W32 384x288 **B = 32** training step, fp32 path vs the oracle run on the box's CPU: output 1e-3,
+  argmax bit-exact, every parameter-gradient norm and ~40 full gradients within 5e-3;
+* the same batch through the bf16 path with the gate of SURVEY.md section 7: argmax equal wherever the
+  fp32 top-2 margin exceeds 2 x the bf16 output tolerance, PCK equal, flipped count reported;
+* W48 training step against a fixture produced by the REFERENCE (tests/golden/g8_w48_train.npz);
+* three fused TrainStep iterations (Adam, SGD-Nesterov) against oracle + torch.optim;
+* the drop-in module refuses a backward through a stale forward; load_pretrained; apply_perceptual_loss;
+  accuracy() against the reference's calc_dists / dist_acc fixture (G12).
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import hrnet_ref, pose_ref  # noqa: E402  (checker only)
+from stlpose_amd import PersonMSELoss, PoseHighResolutionNet, get_max_preds_hrnet  # noqa: E402
+from stlpose_amd.loss import apply_perceptual_loss, perceptual_affine  # noqa: E402
+from stlpose_amd.pose_parsing import accuracy  # noqa: E402
+from stlpose_amd.train_step import TrainStep  # noqa: E402
+from tests.golden.make_golden import FULL_GRAD_KEYS, synth_batch  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _diag(name, lines):
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, name), "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+def _load_synth(model):
+    sd = {k: torch.from_numpy(hrnet_ref.synth_tensor(k, tuple(v.shape))) for k, v in model.state_dict().items()}
+    model.load_state_dict(sd, strict=True)
+    return model
+
+
+# ------------------------------------------------------------------------------------------------ B = 32, the benchmarked plan
+@pytest.fixture(scope="module")
+def oracle_b32():
+    """oracle.RefPoseNet(w32) fp32 on the host: forward + MSE + backward of one 32 x 3 x 384 x 288 batch."""
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    img, tgt, tw = synth_batch(32, 384, 288, seed=4321, sigma=3.0)
+    ref = hrnet_ref.load_synth(hrnet_ref.RefPoseNet("w32")).train()
+    out = ref(torch.from_numpy(img))
+    loss = pose_ref.person_mse_loss(out, torch.from_numpy(tgt), torch.from_numpy(tw))
+    loss.backward()
+    grads = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    bufs = {k: v.clone() for k, v in ref.named_buffers()}
+    o = out.detach().numpy()
+    del ref, out
+    return dict(img=img, tgt=tgt, tw=tw, out=o, loss=float(loss.item()), grads=grads, bufs=bufs)
+
+
+def test_w32_b32_fp32_train_step_vs_oracle(oracle_b32):
+    """The plan the headline is quoted on (B = 32: 256-block split-K, other tile shapes, mask_z fusion on
+    116 sums) on the fp32 path: every weight gradient is compared."""
+    r = oracle_b32
+    m = _load_synth(PoseHighResolutionNet("w32", "fp32")).cuda().train()
+    out = m(torch.from_numpy(r["img"]).cuda())
+    loss = PersonMSELoss()(out, torch.from_numpy(r["tgt"]).cuda(), torch.from_numpy(r["tw"]).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    o = out.detach().cpu().numpy()
+    err = np.abs(o - r["out"]).max() / np.abs(r["out"]).max()
+    p, mv = get_max_preds_hrnet(o)
+    pr, mvr = pose_ref.get_max_preds(r["out"])
+    names = [k for k, _ in m.named_parameters()]
+    got = {k: prm.grad.detach().cpu() for k, prm in m.named_parameters()}
+    nrm = np.array([float(got[k].double().norm()) for k in names])
+    nrm_ref = np.array([float(r["grads"][k].double().norm()) for k in names])
+    rel = np.abs(nrm - nrm_ref) / (nrm_ref + 1e-12)
+    full = []
+    for k in names:
+        if any(re.fullmatch(pat, k) for pat in FULL_GRAD_KEYS):
+            g, gr = got[k].numpy(), r["grads"][k].numpy()
+            full.append((float(np.abs(g - gr).max() / max(np.abs(gr).max(), 1e-12)), k))
+    full.sort(reverse=True)
+    worst = np.argsort(-rel)[:15]
+    _diag("diag_w32_b32_fp32.txt", [f"out rel err {err:.3e}", f"loss {loss.item()} ref {r['loss']}", f"argmax equal {np.array_equal(p, pr)}",
+                                    f"full gradients compared: {len(full)}"]
+          + [f"gradnorm {names[i]}: {nrm[i]:.6e} ref {nrm_ref[i]:.6e} rel {rel[i]:.2e}" for i in worst]
+          + [f"fullgrad {k}: rel {e:.2e}" for e, k in full[:15]])
+    assert err < 1e-3, f"output rel err {err}"
+    assert np.array_equal(p, pr), "heatmap argmax differs from the oracle at B = 32"
+    np.testing.assert_allclose(mv, mvr, rtol=1e-3)
+    assert abs(loss.item() - r["loss"]) < 1e-3 * abs(r["loss"])
+    assert len(full) >= 40
+    assert rel.max() < 5e-3, f"worst gradient norm {names[worst[0]]}: rel {rel.max():.3e}"
+    assert full[0][0] < 5e-3, f"worst full gradient {full[0]}"
+    for k in ("bn1.running_mean", "layer1.3.bn3.running_var", "stage4.2.branches.0.3.bn2.running_var", "stage3.1.fuse_layers.2.0.1.1.running_mean"):
+        np.testing.assert_allclose(dict(m.named_buffers())[k].cpu().numpy(), r["bufs"][k].numpy(), rtol=1e-3, atol=1e-5, err_msg=k)
+
+
+def test_w32_b32_bf16_gate_vs_oracle(oracle_b32):
+    """bf16 storage / fp32 accumulate on the benchmarked batch, SURVEY section 7 gate: output within TOL of the
+    fp32 oracle; argmax equal wherever the oracle's top-2 margin exceeds 2 x TOL x |out|max (a flip below that
+    margin is a near-tie, not an error); PCK(accuracy) equal; gradient norms per top-level module within 10 %."""
+    TOL = 5e-2
+    r = oracle_b32
+    m = _load_synth(PoseHighResolutionNet("w32", "bf16")).cuda().train()
+    out = m(torch.from_numpy(r["img"]).cuda())
+    loss = PersonMSELoss()(out, torch.from_numpy(r["tgt"]).cuda(), torch.from_numpy(r["tw"]).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    o = out.detach().cpu().numpy()
+    absmax = float(np.abs(r["out"]).max())
+    err = float(np.abs(o - r["out"]).max() / absmax)
+    p, _ = get_max_preds_hrnet(o)
+    pr, _ = pose_ref.get_max_preds(r["out"])
+    flat = r["out"].reshape(32, 17, -1)
+    top2 = np.partition(flat, -2, axis=-1)[..., -2:]
+    margin = top2[..., 1] - top2[..., 0]
+    same = (p == pr).all(-1)
+    decisive = margin > 2 * TOL * absmax
+    acc_b = pose_ref.pck_accuracy(o, r["tgt"])
+    acc_r = pose_ref.pck_accuracy(r["out"], r["tgt"])
+    acc_dev = accuracy(out.detach(), torch.from_numpy(r["tgt"]).cuda())
+    gn, gnr = {}, {}
+    for k, prm in m.named_parameters():
+        top = k.split(".")[0]
+        gn[top] = gn.get(top, 0.0) + float((prm.grad.double() ** 2).sum())
+        gnr[top] = gnr.get(top, 0.0) + float((r["grads"][k].double() ** 2).sum())
+    _diag("diag_w32_b32_bf16.txt", [f"out rel err {err:.3e} (bar {TOL})", f"loss {loss.item()} ref {r['loss']}",
+                                    f"argmax: {int(same.sum())}/{same.size} equal, {int((~same).sum())} flipped; decisive maps {int(decisive.sum())}, flipped among them {int((decisive & ~same).sum())}",
+                                    f"smallest margin among flipped / |out|max: {float(margin[~same].max() / absmax) if (~same).any() else 0.0:.3e}",
+                                    f"PCK bf16 {acc_b[1]:.6f} oracle {acc_r[1]:.6f} device accuracy() {acc_dev[1]:.6f}",
+                                    "gradnorm " + " ".join(f"{k}:{np.sqrt(gn[k]):.4e}/{np.sqrt(gnr[k]):.4e}" for k in sorted(gn))])
+    assert err < TOL
+    assert not (decisive & ~same).any(), "argmax flipped on a map whose fp32 top-2 margin exceeds the bf16 tolerance"
+    assert acc_b[1] == acc_r[1] and acc_b[2] == acc_r[2], "PCK differs between the bf16 path and the fp32 oracle"
+    np.testing.assert_allclose(acc_dev[0], acc_b[0], rtol=0, atol=1e-12)
+    assert abs(loss.item() - r["loss"]) < 2e-2 * abs(r["loss"])
+    for k in gn:
+        assert abs(np.sqrt(gn[k]) - np.sqrt(gnr[k])) < 0.1 * np.sqrt(gnr[k]), k
+
+
+# ------------------------------------------------------------------------------------------------ W48 training vs the reference
+def test_w48_train_fp32_vs_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g8_w48_train.npz"))
+    img, tgt, tw = synth_batch(2, 128, 96, seed=48, sigma=2.0)
+    m = _load_synth(PoseHighResolutionNet("w48", "fp32")).cuda().train()
+    out = m(torch.from_numpy(img).cuda())
+    loss = PersonMSELoss()(out, torch.from_numpy(tgt).cuda(), torch.from_numpy(tw).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    o = out.detach().cpu().numpy()
+    err = np.abs(o.reshape(-1)[::16] - g["out_sample"]).max() / float(g["out_absmax"])
+    names = [k for k, _ in m.named_parameters()]
+    assert names == list(g["param_keys"])
+    grads = {k: prm.grad for k, prm in m.named_parameters()}
+    nrm = np.array([float(grads[k].double().norm()) for k in names])
+    rel = np.abs(nrm - g["gradnorm_all"]) / (g["gradnorm_all"] + 1e-12)
+    full = sorted(((float(np.abs(grads[k[5:]].cpu().numpy() - g[k]).max() / max(np.abs(g[k]).max(), 1e-12)), k)
+                   for k in g.files if k.startswith("grad/")), reverse=True)
+    worst = np.argsort(-rel)[:10]
+    _diag("diag_w48_train.txt", [f"out rel err {err:.3e}", f"loss {loss.item()} ref {float(g['loss'])}"]
+          + [f"gradnorm {names[i]}: {nrm[i]:.6e} ref {g['gradnorm_all'][i]:.6e} rel {rel[i]:.2e}" for i in worst]
+          + [f"fullgrad {k}: rel {e:.2e}" for e, k in full[:10]])
+    assert err < 1e-3
+    assert abs(loss.item() - float(g["loss"])) < 1e-3 * abs(float(g["loss"]))
+    assert rel.max() < 5e-3, f"worst gradient norm {names[worst[0]]} rel {rel.max():.3e}"
+    assert len(full) >= 40 and full[0][0] < 5e-3, f"worst full gradient {full[0]}"
+    bn = np.array([float(v.double().norm()) for _, v in m.named_buffers()])
+    np.testing.assert_allclose(bn, g["buffernorm_all"], rtol=1e-3)
+
+
+def test_w48_bf16_train_step_runs_at_cfg3_shape():
+    """BASELINE configs[2] shape on one GPU (W48, 384x288, batch 32, bf16): the 48/96/192/384 widths at the full
+    batch -- finite loss that decreases, finite gradients."""
+    torch.manual_seed(7)
+    m = PoseHighResolutionNet("w48", "bf16").cuda()
+    ts = TrainStep(m, 32, 384, 288, optimizer="adam", lr=1e-3)
+    img, tgt, tw = synth_batch(32, 384, 288, seed=77, sigma=3.0)
+    ts.load_batch(torch.from_numpy(img).cuda(), torch.from_numpy(tgt).cuda(), torch.from_numpy(tw).cuda())
+    losses = [float(ts.step().item()) for _ in range(4)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert torch.isfinite(ts.store.grads).all()
+
+
+# ------------------------------------------------------------------------------------------------ multi-step trajectory
+@pytest.mark.parametrize("opt", ["adam", "sgd"])
+def test_three_train_steps_vs_oracle_and_torch_optim(opt):
+    """Catches a stale weight layout, running-statistics drift and optimiser ordering: three fused steps on
+    three different batches against oracle + torch.optim with the reference's hyper-parameters
+    (model_setup.py:136-141: Adam lr; SGD momentum 0.9, weight decay 5e-4, Nesterov)."""
+    ref = hrnet_ref.load_synth(hrnet_ref.RefPoseNet("tiny")).train()
+    m = _load_synth(PoseHighResolutionNet("tiny", "fp32")).cuda()
+    if opt == "adam":
+        ro = torch.optim.Adam(ref.parameters(), lr=1e-3)
+        ts = TrainStep(m, 2, 96, 64, optimizer="adam", lr=1e-3)
+    else:
+        ro = torch.optim.SGD(ref.parameters(), lr=1e-2, momentum=0.9, weight_decay=5e-4, nesterov=True)
+        ts = TrainStep(m, 2, 96, 64, optimizer="sgd", lr=1e-2, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    for step in range(3):
+        img, tgt, tw = synth_batch(2, 96, 64, seed=300 + step)
+        ro.zero_grad()
+        rl = pose_ref.person_mse_loss(ref(torch.from_numpy(img)), torch.from_numpy(tgt), torch.from_numpy(tw))
+        rl.backward()
+        ro.step()
+        ts.load_batch(torch.from_numpy(img).cuda(), torch.from_numpy(tgt).cuda(), torch.from_numpy(tw).cuda())
+        l = float(ts.step().item())
+        assert abs(l - rl.item()) < 1e-3 * abs(rl.item()), f"step {step}: loss {l} vs {rl.item()}"
+    torch.cuda.synchronize()
+    worst = (0.0, "")
+    sd = m.state_dict()
+    for k, v in ref.state_dict().items():
+        got = sd[k].detach().cpu()
+        if k.endswith("num_batches_tracked"):
+            assert int(got) == int(v) == 3
+            continue
+        if v.dim() == 4 or k.endswith((".weight", ".bias")):
+            d = float((got - v).abs().max())
+            worst = max(worst, (d, k))
+        else:   # running statistics
+            np.testing.assert_allclose(got.numpy(), v.numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+    assert worst[0] < 1e-4, f"weights after 3 {opt} steps differ from oracle + torch.optim: {worst}"
+
+
+# ------------------------------------------------------------------------------------------------ drop-in module hazards
+def test_backward_through_stale_forward_raises():
+    m = _load_synth(PoseHighResolutionNet("tiny", "fp32")).cuda().train()
+    x1, x2 = torch.randn(2, 3, 64, 64).cuda(), torch.randn(2, 3, 64, 64).cuda()
+    o1 = m(x1)
+    o2 = m(x2)            # same plan: overwrites the activations o1's backward needs
+    with pytest.raises(RuntimeError, match="stale forward"):
+        (o1.sum() + o2.sum()).backward()
+    o3 = m(x1)            # the normal pattern keeps working
+    o3.sum().backward()
+    assert m.conv1.weight.grad is not None and torch.isfinite(m.conv1.weight.grad).all()
+    # a different batch size is a different plan: both graphs stay valid
+    oa, ob = m(x1), m(x2[:1])
+    (oa.sum() + ob.sum()).backward()
+
+
+def test_device_without_index_does_not_repack_under_a_train_step():
+    """device('cuda') != device('cuda:0') made the first model(x) after building a TrainStep
+    re-pack the parameters and orphan the optimiser's flat buffers."""
+    m = _load_synth(PoseHighResolutionNet("tiny", "fp32"))
+    ts = TrainStep(m, 2, 64, 64, optimizer="adam", lr=1e-2, device="cuda")
+    store = m._store
+    img, tgt, tw = synth_batch(2, 64, 64, seed=9)
+    m.eval()
+    with torch.no_grad():
+        m(torch.from_numpy(img).cuda())          # validation forward before any training
+    assert m._store is store and m.conv1.weight.data_ptr() == store.master.data_ptr()
+    w0 = store.master.clone()
+    ts.load_batch(torch.from_numpy(img).cuda(), torch.from_numpy(tgt).cuda(), torch.from_numpy(tw).cuda())
+    m.train()
+    ts.step()
+    torch.cuda.synchronize()
+    assert not torch.equal(store.master, w0)
+    flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    assert torch.equal(flat, store.master), "module parameters are no longer views of the trained flat buffer"
+    with pytest.raises(RuntimeError, match="held by a TrainStep"):
+        m._pack(torch.device("cpu"))
+
+
+def test_load_pretrained_init_and_checkpoint(tmp_path):
+    """HRnet.py:470-499: conv ~ N(0, 0.001), BN gamma 1 / beta 0, head bias 0, then a non-strict checkpoint load."""
+    torch.manual_seed(0)
+    m = PoseHighResolutionNet("tiny", "fp32")
+    m.load_pretrained("")
+    assert abs(float(m.conv1.weight.std()) - 1e-3) < 2e-4 and float(m.conv1.weight.abs().max()) < 1e-2
+    assert torch.equal(m.bn1.weight, torch.ones_like(m.bn1.weight)) and torch.count_nonzero(m.bn1.bias) == 0
+    assert torch.count_nonzero(m.final_layer.bias) == 0
+    ref = hrnet_ref.load_synth(hrnet_ref.RefPoseNet("tiny"))
+    sd = ref.state_dict()
+    sd.pop("final_layer.bias")              # non-strict: a missing key keeps the fresh init
+    sd["not.in.the.model"] = torch.zeros(1)
+    path = str(tmp_path / "w.pth")
+    torch.save(sd, path)
+    m.load_pretrained(path)
+    assert torch.equal(m.layer1[0].conv2.weight, sd["layer1.0.conv2.weight"])
+    assert torch.equal(m.stage2[0].branches[1][0].bn1.running_var, sd["stage2.0.branches.1.0.bn1.running_var"])
+    assert torch.count_nonzero(m.final_layer.bias) == 0
+    with pytest.raises(ValueError, match="is not exist"):
+        m.load_pretrained(str(tmp_path / "missing.pth"))
+    # the loaded weights are what the device path computes with
+    m = m.cuda().eval()
+    ref.final_layer.bias.data.zero_()
+    x = torch.randn(1, 3, 64, 64)
+    with torch.no_grad():
+        err = (m(x.cuda()).cpu() - ref.eval()(x)).abs().max() / ref(x).abs().max()
+    assert err < 1e-3
+
+
+def test_apply_perceptual_loss_matches_reference_formulas():
+    """lib/loss.py:97-150 (scalar arithmetic, restated here as the expected values) + the (scale, offset) form the
+    fused step uses + the fused step actually applying it."""
+    loss = torch.tensor(0.37).cuda()
+    perc = torch.tensor([0.2, 0.6, 0.1])
+    class P:  # noqa: E306
+        use_perceptual_loss = False
+    base = {"training": {}, "dataset": {"dataset_name": "styled_coco"}}
+    assert apply_perceptual_loss({"training": {}, "dataset": {"dataset_name": "coco"}}, P, loss, perc) is loss
+    assert apply_perceptual_loss(base, P, loss, perc) is loss                               # flag off
+    e = {"training": {"perceptual_loss": True, "lambda_D": None, "lambda_P": None}, "dataset": {"dataset_name": "styled_coco"}}
+    assert float(apply_perceptual_loss(e, P, loss, perc)) == pytest.approx(0.37 * (1 + 0.3), rel=1e-6)
+    assert perceptual_affine(e, P, perc) == pytest.approx((1.3, 0.0))
+    e2 = {"training": {"perceptual_loss": True, "lambda_D": 0.8, "lambda_P": 0.5}, "dataset": {"dataset_name": "styled_coco"}}
+    assert float(apply_perceptual_loss(e2, P, loss, perc)) == pytest.approx(0.8 * 0.37 + 0.5 * 0.3, rel=1e-6)
+    assert perceptual_affine(e2, P, perc) == pytest.approx((0.8, 0.15))
+    e3 = {"training": {"perceptual_loss": True, "lambda_D": None, "lambda_P": None, "perceptual_weight": "mul"},
+          "dataset": {"dataset_name": "styled_coco"}}
+    with pytest.raises(SystemExit):
+        apply_perceptual_loss(e3, P, loss, perc)
+    # fused step: gradients scale with `scale`, the reported loss is scale * mse + offset
+    img, tgt, tw = synth_batch(2, 64, 64, seed=21)
+    res = []
+    for scale, off in ((1.0, 0.0), (0.8, 0.15)):
+        m = _load_synth(PoseHighResolutionNet("tiny", "fp32"))
+        ts = TrainStep(m, 2, 64, 64, optimizer="sgd", lr=0.0, momentum=0.0)
+        ts.load_batch(torch.from_numpy(img).cuda(), torch.from_numpy(tgt).cuda(), torch.from_numpy(tw).cuda())
+        ts.set_loss_affine(scale, off)
+        l = float(ts.step().item())
+        res.append((l, ts.store.grads.clone()))
+    assert res[1][0] == pytest.approx(0.8 * res[0][0] + 0.15, rel=1e-5)
+    assert torch.allclose(res[1][1], 0.8 * res[0][1], rtol=1e-4, atol=1e-9)
+
+
+def test_accuracy_matches_reference_calc_dists_fixture(golden_dir):
+    """G12 = the reference's own get_max_preds_hrnet + calc_dists + dist_acc (lib/metrics.py:268-318)."""
+    g = np.load(os.path.join(golden_dir, "g12_metrics.npz"))
+    acc, avg, cnt, pred = accuracy(torch.from_numpy(g["output"]).cuda(), torch.from_numpy(g["target"]).cuda())
+    np.testing.assert_allclose(acc, g["acc"], rtol=0, atol=1e-12)
+    assert avg == pytest.approx(float(g["avg_acc"]), abs=1e-12) and cnt == int(g["cnt"])
+    assert np.array_equal(pred, g["pred"])
+    acc_o = pose_ref.pck_accuracy(g["output"], g["target"])
+    np.testing.assert_allclose(acc_o[0], g["acc"], rtol=0, atol=1e-12)

@@ -116,3 +116,37 @@ def test_evaluator_end_to_end_on_synthetic_loader():
     assert np.isclose(stats[0], 1.0) and np.isclose(stats[5], 1.0)
     out2 = ev.evaluate_model(loader, gt_annotations=gts)
     assert np.allclose(out2["stats"][[0, 5]], 1.0)
+
+
+def test_checkpoints_hold_the_trained_weights_and_sgd_resume_keeps_momentum(tmp_path):
+    """(high) a validation epoch before training must not re-pack the model away from the optimiser's
+    flat buffers -- the saved weights are the TRAINED ones; (low) resuming SGD continues from the momentum buffer."""
+    B, H, W = 2, 96, 64
+    exp = str(tmp_path / "d")
+    os.makedirs(exp)
+    torch.manual_seed(12)
+    t = Trainer(exp, _exp_data(1, H, W, optimizer="sgd", scheduler="step"), _loader(4, B, H, W, 6), _loader(5, B, H, W, 7), B,
+                arch="tiny", compute_dtype="fp32")   # default device "cuda" (no index), like the reference's scripts
+    t.setup_model()
+    init = t.ts.store.master.clone()
+    t.training_loop()
+    ck = torch.load(os.path.join(exp, "models", "checkpoint_epoch_final.pth"), weights_only=False)
+    flat = torch.cat([ck["model_state_dict"]["module." + k].reshape(-1) for k, _ in t.ts.store.reg.params])
+    assert torch.equal(flat, t.ts.store.master.cpu()), "checkpoint does not hold the flat buffer the optimiser trained"
+    assert not torch.equal(flat, init.cpu()), "checkpoint still holds the initial weights"
+    assert float(t.ts.m.abs().max()) > 0
+    # resume: the first step after loading must use the loaded momentum buffer (torch.optim.SGD semantics)
+    t2 = Trainer(exp, _exp_data(2, H, W, optimizer="sgd", scheduler="step"), _loader(1, B, H, W, 8), _loader(5, B, H, W, 7), B,
+                 arch="tiny", compute_dtype="fp32", checkpoint=os.path.join(exp, "models", "checkpoint_epoch_final.pth"),
+                 resume_training=True)
+    t2.setup_model()
+    assert int(t2.ts.step_count.item()) >= 1
+    mom = t2.ts.m.clone()
+    w0 = t2.ts.store.master.clone()
+    t2.train_epoch(1)
+    torch.cuda.synchronize()
+    g = t2.ts.store.grads
+    lr, wd = 1e-3 * 0.5, 5e-4     # one StepLR decay already applied in the first run
+    gg = g + wd * w0
+    expect = w0 - float(t2.lr) * (0.9 * mom + gg)      # b = mu * b_loaded + g ; p -= lr * b   (no Nesterov)
+    assert torch.allclose(t2.ts.store.master, expect, rtol=1e-4, atol=1e-7)

@@ -1,5 +1,9 @@
-"""GPU: VGG16 perceptual loss on the HIP kernels vs the torch-ops restatement (oracle/vgg_ref.py,
-parity UNPINNED: the reference's VGG needs torchvision + downloaded weights; synthetic weights here)."""
+"""GPU: VGG16 perceptual loss on the HIP kernels vs fixture G10 (the reference's own VGGPerceptualLoss run on a
+torchvision-free VGG16-D layer list, synthetic weights) and vs the torch-ops restatement (oracle/vgg_ref.py,
+itself pinned by G10) at further shapes, including BASELINE configs[3]'s 16 x 3 x 512 x 512."""
+import os
+
+import numpy as np
 import pytest
 import torch
 
@@ -50,3 +54,29 @@ def test_offline_perceptual_loss_dict(tmp_path):
     for name, a, b in pairs:
         ref = vgg_ref.vgg_perceptual_loss(a[None], b[None], w, resize=True).item()
         assert abs(d[name] - ref) <= 1e-3 * abs(ref)
+
+
+@pytest.mark.parametrize("tag", ["rs_rgb", "rs_gray", "nr_rgb", "nr_odd", "nr_gray"])
+def test_vgg_matches_reference_fixture_g10(golden_dir, tag):
+    """resize=True / False, 1- and 3-channel inputs, and a size that is not a multiple of 8 (the max-pools floor)."""
+    g = np.load(os.path.join(golden_dir, "g10_vgg.npz"))
+    m = VGGPerceptualLoss(resize=bool(g[f"{tag}_resize"]), state_dict=vgg_ref.synth_vgg_weights(), compute_dtype="fp32").cuda()
+    got = m(torch.from_numpy(g[f"{tag}_in"]).cuda(), torch.from_numpy(g[f"{tag}_tg"]).cuda()).item()
+    ref = float(g[f"{tag}_loss"])
+    assert abs(got - ref) <= 1e-3 * abs(ref), (tag, got, ref)
+
+
+def test_vgg_cfg4_shape_16x512x512_vs_oracle():
+    """BASELINE configs[3] shape: batch 16, 512 x 512, fp32, resize=False (2 x 16 images through the VGG16 slices)."""
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    w = vgg_ref.synth_vgg_weights()
+    g = torch.Generator().manual_seed(16)
+    a = torch.rand(16, 3, 512, 512, generator=g)
+    b = (a + 0.2 * torch.randn(16, 3, 512, 512, generator=g)).clamp_(0, 1)
+    with torch.no_grad():
+        ref = sum(vgg_ref.vgg_perceptual_loss(a[i:i + 4], b[i:i + 4], w, resize=False).item() for i in range(0, 16, 4)) / 4
+    m = VGGPerceptualLoss(resize=False, state_dict=w, compute_dtype="fp32").cuda()
+    got = m(a.cuda(), b.cuda()).item()
+    assert abs(got - ref) <= 1e-3 * abs(ref), (got, ref)
+    mb = VGGPerceptualLoss(resize=False, state_dict=w, compute_dtype="bf16").cuda()
+    assert abs(mb(a.cuda(), b.cuda()).item() - ref) <= 3e-2 * abs(ref)
