@@ -111,7 +111,24 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32-path and VGG cfg4 legs")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks as CHILD processes (one per GPU, RCCL)
+        # before this process has touched the GPU, relay their output (rank 0 prints the JSON line) and
+        # exit with their code.  Never exec over a process that initialised HIP.
+        import socket
+        import subprocess
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -183,7 +200,7 @@ def main():
                         algorithmic_GBps=round(dom["gbs"], 1), hbm_frac=round(dom["gbs"] / HBM_PEAK, 4),
                         algorithmic_bytes_per_launch=round(dom["gbs"] * dom["ms"] * 1e6),
                         traffic_unit="HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)")
-        out = dict(metric="images/sec/GPU HRNet-W32 384x288 train step; PCKh@0.5 parity", value=round(value, 2),
+        out = dict(metric=f"images/sec/GPU HRNet-{a.arch.upper()} {a.height}x{a.width} train step; PCKh@0.5 parity", value=round(value, 2),
                    unit="images/sec", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.dtype, data="synthetic",
                    config=dict(workload=f"HRNet-{a.arch.upper()} {a.height}x{a.width} bs={a.batch}/GPU train step "
