@@ -75,6 +75,16 @@ typedef struct stl_conv {
                               z <= 0).  With addend / mask_y (mask_bn.relu = 0) / red this is the backward of a
                               residual block end  z = ReLU(BN(y) + x)  fused into the data gradient that
                               produces the last contribution to dz (HRnet.py:58-59,99-100). */
+    /* Fused backward of a 3x3 stride-1 C -> C convolution (aten::convolution_backward, data AND weight part in
+     * one launch): when wg_partial != NULL this call is the data gradient described above (src = BNBWD gradient
+     * of the conv's output, w = transposed filters) and ALSO accumulates the weight gradient
+     * dw[co][tap][ci] = sum_pixels g[pixel][co] * wg_h(pixel + tap - 1)[ci] from the same staged tiles into
+     * wg_partial[s][C][9][C] (fp32, s < wg_nsplit split-K slabs, summed later by stl_reduce_slabs).
+     * Requires ks 3, stride 1, stuff 0, Ci == Co == C, C % 32 == 0, C <= 64, src.mode BNBWD;
+     * wg_nsplit = number of pixel groups (grid = wg_nsplit * C/32 blocks), a multiple of 8. */
+    stl_src wg_h;          /* the conv's forward input (PLAIN or BN source), [B,Ho,Wo,C]     */
+    float* wg_partial;     /* [wg_nsplit][C][9][C] or NULL                                  */
+    int32_t wg_nsplit;
 } stl_conv;
 int stl_conv_forward(const stl_conv* p, void* stream);
 /* Fill p->shape / p->TH / p->TW once (host-side tile search) so that launches are cheap. */

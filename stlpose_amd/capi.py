@@ -26,7 +26,8 @@ class Conv(C.Structure):
     _fields_ = [("dtype", i32), ("B", i32), ("Hi", i32), ("Wi", i32), ("Ci", i32), ("Ho", i32), ("Wo", i32),
                 ("Co", i32), ("ks", i32), ("stride", i32), ("stuff", i32), ("TH", i32), ("TW", i32), ("shape", i32),
                 ("src", Src), ("w", vp), ("out", vp), ("bias", vp), ("out_relu", i32), ("out_stats", vp),
-                ("addend", vp), ("mask_y", vp), ("mask_bn", Src), ("red", vp), ("mask_z", vp)]
+                ("addend", vp), ("mask_y", vp), ("mask_bn", Src), ("red", vp), ("mask_z", vp),
+                ("wg_h", Src), ("partial", vp), ("wg_nsplit", i32)]   # `partial` = wg_partial (fused weight gradient slabs)
 
 
 class Wgrad(C.Structure):

@@ -45,7 +45,35 @@ struct ConvK {
     int dbg;
     float r_HC, r_TW, r_tc, r_PI, r_vp;  // reciprocals for fdiv
     int ny;  // output-channel blocks per pixel tile (they are the FAST block dimension, see kernel)
+    // fused weight gradient (p.wg_partial != NULL): LDS offsets of the h-slab halo tile / its BN constants,
+    // bytes per h pixel, K steps (of 4*KV pixels) that cover the pixel tile
+    int off_h, off_ch, psh, nks;
 };
+
+// transposed LDS fragment reads for the fused weight gradient (K = pixels; same forms as wgrad.hip)
+template <typename T>
+__device__ __forceinline__ V16 cfrag_tr(const char* base, const int* rowoff, int colbyte, int lane);
+template <>
+__device__ __forceinline__ V16 cfrag_tr<__bf16>(const char* base, const int* rowoff, int colbyte, int lane) {
+    V16 v;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const char* ptr = base + rowoff[h] + colbyte + (lane & 3) * 8;
+        s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(uintptr_t)(uint32_t)(uintptr_t)ptr);
+        const uint64_t bits = __builtin_bit_cast(uint64_t, r);
+        v.w[2 * h] = (uint32_t)bits;
+        v.w[2 * h + 1] = (uint32_t)(bits >> 32);
+    }
+    return v;
+}
+template <>
+__device__ __forceinline__ V16 cfrag_tr<float>(const char* base, const int* rowoff, int colbyte, int lane) {
+    V16 v;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v.w[s] = *reinterpret_cast<const uint32_t*>(base + rowoff[s] + colbyte + (lane & 15) * 4);
+    return v;
+}
 
 template <typename T>
 __device__ __forceinline__ void load4(const void* base, size_t elem, float* f) {
@@ -77,11 +105,26 @@ __device__ __forceinline__ void store4(void* base, size_t elem, const float* f) 
 // WR: 1 = the filters are known to be LDS-resident (whole K in one chunk): the per-stage filter
 // staging registers and descriptors do not exist in that instantiation (no spills at 128 VGPRs);
 // -1 = decided at run time (k.wres)
-template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, int OCC, int WR>
+// NCO > 0: FUSED BACKWARD of a 3x3 stride-1 C -> C convolution (NCO = C / CK input chunks of the data
+// gradient = output-channel chunks of the forward conv).  The block is the 128-pixel x 32-channel data-gradient
+// block (WM 4, WN 1, MT 2, NTW 2); in every stage (tile, chunk) it ALSO accumulates the weight gradient
+// dw[co in chunk][tap][ci in the block's 32-channel slab] += sum_pixels g[pixel][co] * h[pixel + tap][ci] from
+// the g halo tile it has staged for the data gradient anyway (read transposed: K = pixels) and a halo tile of
+// the conv's forward input h (same halo geometry, staged once per tile).  dt and y are fetched once for both
+// gradients, one launch instead of two; every wave owns whole output tiles (no cross-wave reduction) and keeps
+// them in registers across the block's tiles; the block writes one split-K slab at the end.
+template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, int OCC, int WR, int NCO = 0>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const ConvK k) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTHR = 64 * WM * WN;
     constexpr int KV = ET<T>::KV, CK = ET<T>::CK, TAPS = KS * KS;
+    constexpr bool FW = NCO > 0;
+    static_assert(!FW || (KS == 3 && WM == 4 && WN == 1 && MT == 2 && NTW == 2 && Q), "fused weight gradient: 3x3, 128 px x 32 channels, BNBWD source");
+    constexpr int NH = FW ? (sizeof(T) == 2 ? 1 : 2) : 1;   // 16-byte h vectors per staging slot (32 channels per pixel)
+    constexpr int WKS = 4 * KV;                              // pixels per MFMA K step of the weight gradient
+    constexpr int WNR = sizeof(T) == 2 ? 2 : 4;              // row offsets per transposed fragment
+    constexpr int CT = CK / 16;                              // 16-channel tiles per chunk (2 bf16, 1 fp32)
+    constexpr int NJ = CT == 2 ? TAPS : (TAPS + 1) / 2;      // weight-gradient accumulator tiles per wave and chunk
     constexpr int BCO = WN * NTW * 16;
     constexpr int ROWB = TAPS * 64 + 32;
     constexpr int NVB = (BCO * TAPS * 4 + NTHR - 1) / NTHR;
@@ -121,6 +164,16 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
         }
     }
 
+    float* hcs = reinterpret_cast<float*>(smem + k.off_ch);  // fused: [2][32] BN affine of the h slab
+    char* sH = smem + k.off_h;
+    if constexpr (FW) {
+        if (tid < 32) {
+            float a = 1.f, b = 0.f, cc = 0.f;
+            if (p.wg_h.mode != STL_SRC_PLAIN) src_consts(p.wg_h, n0 + tid, p.Co, a, b, cc);
+            hcs[tid] = a, hcs[32 + tid] = b;
+        }
+        if (tid < PSA / 16) *reinterpret_cast<V16*>(sA + k.HP * PSA + tid * 16) = zero16();   // zero pixel row behind the halo tile
+    }
     STAMP(1);
     // ---- loop-invariant per-thread descriptors
     int a_rc[NVA];  // (halo row << 16) | halo col, -1 when this slot is unused
@@ -166,6 +219,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 
     STAMP(2);
     V16 ra[NVA], rq[Q ? NVA : 1], rb[NVB];
+    V16 rh[FW ? NVA : 1][NH];
     int a_go[NVA];
 
     auto tile_setup = [&](int t, int* go) {
@@ -201,6 +255,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
             const int off = (go[i] >= 0 && chok) ? go[i] + k0 : 0;
             ra[i] = ldg16((const char*)p.src.x + (size_t)off * sizeof(T));
             if (Q) rq[i] = ldg16((const char*)p.src.y + (size_t)off * sizeof(T));
+            if constexpr (FW) {   // h slab of the same halo pixel (Ci == Co): only with the first chunk of a tile
+                const int hoff = (go[i] >= 0 && en && k0 == 0) ? go[i] + n0 : 0;
+#pragma unroll
+                for (int j = 0; j < NH; ++j) rh[i][j] = ldg16((const char*)p.wg_h.x + (size_t)(hoff + 4 * KV * j) * sizeof(T));
+            }
         }
         if (!wres) {
 #pragma unroll
@@ -211,6 +270,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
         }
     };
     const float relu_lo = p.src.relu ? 0.f : -INFINITY;
+    const float relu_lo_h = (FW && p.wg_h.relu) ? 0.f : -INFINITY;
     auto write_lds = [&](const int* go, int k0) {
         const int ch = k0 + a_part * KV;
 #pragma unroll
@@ -226,6 +286,18 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
             mask16(val, ok);  // zero padding applies AFTER the transform
             const int v = tid + i * NTHR;
             *reinterpret_cast<V16*>(sA + (v >> 2) * PSA + (v & 3) * 16) = val;
+            if constexpr (FW) {
+                if (k0 == 0) {
+#pragma unroll
+                    for (int j = 0; j < NH; ++j) {
+                        V16 hv = rh[i][j];
+                        const int cl = (a_part + 4 * j) * KV;
+                        if (p.wg_h.mode != STL_SRC_PLAIN) hv = xform_bn<T>(hv, hcs + cl, hcs + 32 + cl, relu_lo_h);
+                        mask16(hv, go[i] >= 0);   // zero padding applies AFTER the transform
+                        *reinterpret_cast<V16*>(sH + (v >> 2) * k.psh + (a_part + 4 * j) * 16) = hv;
+                    }
+                }
+            }
         }
         if (!wres) {
 #pragma unroll
@@ -282,6 +354,50 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 #pragma unroll
         for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- fused weight gradient: accumulators and the lane's transposed-read row offsets
+    // wave w owns ci tile nt = w & 1 of the slab; bf16: co tile mt = w >> 1 of the chunk, all 9 taps;
+    // fp32 (one co tile per chunk): taps 2j + (w >> 1).
+    f32x4 accw[FW ? NCO : 1][FW ? NJ : 1];
+    const int w_nt = wave & 1, w_hw = wave >> 1;
+    if constexpr (FW) {
+#pragma unroll
+        for (int c = 0; c < NCO; ++c)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) accw[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // one chunk's weight-gradient MFMAs out of the staged tiles.  The K-step loop is a real loop (row offsets
+    // recomputed per step, ~20 VALU against 9+ MFMAs): unrolled, hipcc hoists every fragment read of the tile
+    // and spills ~70 registers.
+    auto wg_mfma = [&](f32x4* aw) {
+        const int acol = (CT == 2 ? w_hw : 0) * 16 * (int)sizeof(T), bcol = w_nt * 16 * (int)sizeof(T);
+#pragma unroll 1
+        for (int s_ = 0; s_ < k.nks; ++s_) {
+            int og[WNR], oh[WNR];   // rows of this lane's pixels in the g / h halo tiles
+#pragma unroll
+            for (int i = 0; i < WNR; ++i) {
+                int m;
+                if constexpr (sizeof(T) == 2)
+                    m = s_ * WKS + 8 * g + 4 * i + (r16 >> 2);
+                else
+                    m = s_ * WKS + 4 * g + i;
+                const bool in = m < tilepx;
+                const int mm = in ? m : 0;
+                const int ty = fdiv(mm, k.r_TW), tx = mm - ty * k.TW;
+                og[i] = in ? ((ty + 1) * k.HC + tx + 1) * PSA : k.HP * PSA;   // beyond the tile: the zero row
+                oh[i] = (ty * k.HC + tx) * k.psh;                             // tap (0, 0) corner of the pixel's 3x3 window
+            }
+            const V16 af = cfrag_tr<T>(sA, og, acol, lane);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int tap = CT == 2 ? j : 2 * j + w_hw;
+                if (tap < TAPS) {
+                    const V16 bf = cfrag_tr<T>(sH + ((tap / KS) * k.HC + (tap % KS)) * k.psh, oh, bcol, lane);
+                    mma16<T>(aw[j], af, bf);
+                }
+            }
+        }
+    };
+
     // flat loop over stages (tile, chunk); exactly ONE issue() site inside the loop so that the
     // staging registers need no PHI copies (which would force a vmcnt(0) before the MFMAs)
     while (have) {
@@ -321,6 +437,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 #pragma unroll
                     for (int ni = 0; ni < NTW; ++ni) mma16<T>(acc[mi][ni], wf[tap & 1][ni], xf[tap & 1][mi]);
             }
+        }
+        if constexpr (FW) {
+#pragma unroll
+            for (int c = 0; c < NCO; ++c)
+                if (ch0 == c) wg_mfma(accw[c]);   // static accumulator index per chunk
         }
         __syncthreads();  // everyone is done with sA/sB of this stage
         if (ch0 == 0) STAMP(7);
@@ -372,6 +493,25 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
                 atomicAdd(dst + (size_t)(blockIdx.x & (STL_NSHARD - 1)) * 2 * p.Co + which * p.Co + n0 + cl, (double)s);
         }
     }
+    if constexpr (FW) {
+        // ---- weight-gradient slab of this block's pixel group: partial[sid][co][tap][ci], fp32
+        // accw[c][j][r] = dw[co = c*CK + mt*16 + 4g + r][tap_j][ci = n0 + nt*16 + r16]
+        const int sid = xcd * nx + lx;
+        float* slab = p.wg_partial + (size_t)sid * p.Ci * TAPS * p.Co;
+        const int ci = n0 + w_nt * 16 + r16;
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) {
+            const int co = c * CK + (CT == 2 ? w_hw : 0) * 16 + 4 * g;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int tap = CT == 2 ? j : 2 * j + w_hw;
+                if (tap < TAPS) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slab[((size_t)(co + r) * TAPS + tap) * p.Co + ci] = accw[c][j][r];
+                }
+            }
+        }
+    }
     STAMP(11);
     if (k.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[13] = __builtin_amdgcn_s_memtime();
 }
@@ -379,17 +519,28 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 #include "conv_ws.inc"
 #include "conv1x1.inc"
 
-template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, int OCC = 1, int WR = -1>
+template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, int OCC = 1, int WR = -1, int NCO = 0>
 int launch(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, OCC, WR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, OCC, WR, NCO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, OCC, WR>), grid, dim3(64 * WM * WN), lds, st, k);
+    hipLaunchKernelGGL((conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, OCC, WR, NCO>), grid, dim3(64 * WM * WN), lds, st, k);
     STL_LAUNCH_CHECK("conv_core");
     return 0;
+}
+
+// fused data + weight gradient (NCO chunks of CK channels): the 128 px x 32 channel block shape only
+template <typename T>
+int dispatch_fused(int nco, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+    switch (nco) {
+        case 1: return launch<T, 3, 4, 1, 2, 2, 3, true, 2, 1, 1>(k, grid, lds, st);    // bf16 C = 32: filters resident
+        case 2: return launch<T, 3, 4, 1, 2, 2, 3, true, 2, -1, 2>(k, grid, lds, st);   // bf16 C = 64 / fp32 C = 32
+        case 4: return launch<T, 3, 4, 1, 2, 2, 3, true, 1, -1, 4>(k, grid, lds, st);   // fp32 C = 64
+    }
+    return stl_set_error("conv(fused): %d chunks not supported", nco);
 }
 
 // block shapes: 0 = 128 px x 64 co (4 waves), 1 = 512 px x 32 co, 2 = 256 px x 64 co, 3 = 256 px x 128 co (8 waves),
@@ -457,7 +608,8 @@ size_t lds_bytes(const stl_conv& p, int shape, int TH, int TW, int ck, ConvK* ou
     off += 4 * bco * 4;
     off = (off + 15) & ~15;
     const int off_a = off;
-    const int sz_a = ((HR * HC * PSA) + 15) & ~15;
+    const bool fused = p.wg_partial != nullptr;
+    const int sz_a = (((HR * HC + (fused ? 1 : 0)) * PSA) + 15) & ~15;   // fused: + one zero pixel row
     off += sz_a * (ws ? 2 : 1);
     const int off_b = off;
     const int sz_b = bco * (taps * 64 + 32);
@@ -467,7 +619,17 @@ size_t lds_bytes(const stl_conv& p, int shape, int TH, int TW, int ck, ConvK* ou
     const int off_red = off_a;  // reused after the last stage
     const int red = 8 * 2 * bco * 4;
     if (off - off_a < red) off = off_a + red;
+    int off_ch = 0, off_h = 0;
+    const int psh = 32 * (ck == 32 ? 2 : 4) + 32;   // 32 channels per h pixel (64 B bf16 / 128 B fp32) + 32 B pad
+    if (fused) {
+        off = (off + 15) & ~15;
+        off_ch = off;
+        off += 2 * 32 * 4;
+        off_h = off;
+        off += HR * HC * psh;
+    }
     if (out) {
+        out->off_ch = off_ch, out->off_h = off_h, out->psh = psh;
         out->HR = HR, out->HC = HC, out->HP = HR * HC, out->nchunks = nchunks, out->cipad = cipad;
         out->off_cs = 0, out->off_cm = off_cm, out->off_a = off_a, out->off_b = off_b, out->off_red = off_red;
         out->sz_a = ws ? sz_a : 0, out->sz_b = (ws && !resident) ? sz_b : 0;
@@ -486,13 +648,13 @@ Plan choose_plan(const stl_conv& p, int ck) {
         if (shape == 3) continue;  // 256x128 block spills registers; reachable via STL_CONV_SHAPE only
         // 128 px x 32 co blocks (four per CU) win in isolation for the C<=32 3x3 layers (21.7 vs 28.2 us)
         const int s4_maxco = getenv("STL_CONV_SHAPE4_MAXCO") ? atoi(getenv("STL_CONV_SHAPE4_MAXCO")) : 32;
-        const bool c32 = !getenv("STL_CONV_NO_C32_SHAPE4") && p.Co <= s4_maxco && p.stride == 1 && p.ks == 3;
+        const bool c32 = p.wg_partial || (!getenv("STL_CONV_NO_C32_SHAPE4") && p.Co <= s4_maxco && p.stride == 1 && p.ks == 3);
         if (shape == 4 && !c32) continue;
         if (c32 && shape != 4) continue;
         // kernel family: measured on MI355X (tools/conv_probe6.py; end to end the threshold Co >= 256 is the better one) the wave-specialised kernel wins for
         // stride-2 convs and for the small, deep maps (Co >= 256), the uniform kernel elsewhere
         const int ws_minco = getenv("STL_CONV_WS_MINCO") ? atoi(getenv("STL_CONV_WS_MINCO")) : 256;
-        const int want_ws = getenv("STL_CONV_WS") ? atoi(getenv("STL_CONV_WS"))
+        const int want_ws = p.wg_partial ? 0 : getenv("STL_CONV_WS") ? atoi(getenv("STL_CONV_WS"))
                                                   : ((p.stride == 2 || (p.ks == 3 && p.Co >= ws_minco && (int64_t)p.B * p.Ho * p.Wo <= 16384)) ? 1 : 0);
         if (sh.ws != want_ws) continue;
         if (want_ws && !getenv("STL_CONV_WS") && shape != 7) continue;
@@ -505,8 +667,9 @@ Plan choose_plan(const stl_conv& p, int ck) {
             const int hr = (th - 1) * p.stride + p.ks, hc = (tw - 1) * p.stride + p.ks;
             const int nva = ceil_div(hr * hc * 4, sh.lthr);
             if (nva > sh.nva_max) continue;
+            if (p.wg_partial && nva > 3) continue;   // fused backward: one instantiation (3 staging vectors per thread)
             const size_t lds = lds_bytes(p, shape, th, tw, ck, nullptr);
-            if (shape == 4 && lds > 40 * 1024 && nva <= 3) continue;  // keep four blocks per CU
+            if (shape == 4 && !p.wg_partial && lds > 40 * 1024 && nva <= 3) continue;  // keep four blocks per CU
             if (lds > 158 * 1024) continue;
             const double tiles = (double)ceil_div(vrows, th) * ceil_div(p.Wo, tw);
             // cost model (arbitrary units): MFMA work of all launched tiles (padding included), the
@@ -593,6 +756,15 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     STL_CHECK(!p.red || p.mask_y, "conv: red needs mask_y");
     STL_CHECK(!p.mask_y || (p.mask_bn.gamma && p.mask_bn.beta && (p.mask_bn.stats || (p.mask_bn.rmean && p.mask_bn.rvar))), "conv: mask BN incomplete");
 
+    const bool fused = p.wg_partial != nullptr;
+    if (fused) {
+        STL_CHECK(p.ks == 3 && p.stride == 1 && !p.stuff, "conv(fused): 3x3 stride 1 only");
+        STL_CHECK(p.Ci == p.Co && p.Ci % 32 == 0 && p.Ci <= 64, "conv(fused): Ci == Co == C with C %% 32 == 0 and C <= 64 (got %d, %d)", p.Ci, p.Co);
+        STL_CHECK(p.src.mode == STL_SRC_BNBWD, "conv(fused): the gradient source must be BNBWD");
+        STL_CHECK(p.wg_h.x && (p.wg_h.mode == STL_SRC_PLAIN || p.wg_h.mode == STL_SRC_BN), "conv(fused): wg_h must be a PLAIN or BN source");
+        STL_CHECK(p.wg_h.mode != STL_SRC_BN || (p.wg_h.gamma && p.wg_h.beta && (p.wg_h.stats || (p.wg_h.rmean && p.wg_h.rvar))), "conv(fused): wg_h BN source incomplete");
+        STL_CHECK(p.wg_nsplit >= 8 && p.wg_nsplit % 8 == 0, "conv(fused): wg_nsplit must be a positive multiple of 8 (got %d)", p.wg_nsplit);
+    }
     if (use_1x1(p))  // wide 1x1 convolutions: streaming GEMM kernel (conv1x1.inc)
         return p.dtype == STL_BF16 ? run_1x1<__bf16>(p, (hipStream_t)stream) : run_1x1<float>(p, (hipStream_t)stream);
 
@@ -615,6 +787,7 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     }
     ConvK k;
     k.p = p;
+    k.nks = 0;
     k.dbg = getenv("STL_CONV_STAMPS") ? 1 : 0;
     k.seff = p.stride;
     k.pad = pad;
@@ -641,11 +814,18 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     if (gx > cap) gx = cap;
     dim3 grid(gx * k.ny, 1);
     const int nva = ceil_div(k.HP * 4, sh.lthr);
+    if (fused) {
+        STL_CHECK(plan.shape == 4 && nva <= 3, "conv(fused): needs the 128 px x 32 channel block shape with a halo of at most 192 pixels (shape %d, %d px)", plan.shape, k.HP);
+        k.nks = ceil_div(plan.TH * plan.TW, 4 * kv);
+        grid = dim3(p.wg_nsplit * k.ny, 1);   // every pixel group writes one slab, tiles or not
+    }
     if (getenv("STL_CONV_DEBUG"))
         fprintf(stderr, "[stl conv] %dx%d Ci%d Co%d ks%d s%d: shape=%d tile=%dx%d npt=%d grid=(%d x %d) lds=%zu nva=%d nchunks=%d\n", p.Ho,
                 p.Wo, p.Ci, p.Co, p.ks, p.stride, plan.shape, plan.TH, plan.TW, k.npt, gx, k.ny, lds, nva, k.nchunks);
     hipStream_t st = (hipStream_t)stream;
     const bool q = p.src.mode == STL_SRC_BNBWD;
+    if (fused)
+        return p.dtype == STL_BF16 ? dispatch_fused<__bf16>(k.nchunks, k, grid, lds, st) : dispatch_fused<float>(k.nchunks, k, grid, lds, st);
 #define DISPATCH(T)                                                                                      \
     if (p.ks == 3)                                                                                       \
         return q ? dispatch<T, 3, true>(plan.shape, nva, k, grid, lds, st) : dispatch<T, 3, false>(plan.shape, nva, k, grid, lds, st); \

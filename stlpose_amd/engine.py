@@ -332,6 +332,7 @@ class Engine:
         self.dout = torch.zeros_like(self.out)
         producer = {id(n[2]): n for n in self.tape if n[0] == "fuse"}
         fuse_block_end = os.environ.get("STLPOSE_FUSE_BLOCK_END", "1") != "0"
+        fused_bwd = os.environ.get("STLPOSE_FUSED_BWD", "1") != "0"
         # ---- gradient buckets: contiguous suffixes of the flat gradient buffer, closed as soon as every
         # parameter in them has its slabs / BatchNorm reductions complete (backward finishes the last
         # layers first).  Each bucket gets one ranged slab reduction + BN-gradient launch inside the
@@ -428,48 +429,14 @@ class Engine:
                 x.bwd_seen += 1
                 assert y.consumers == 1 and y.dt is not None, f"{ci.key}: BN activation must have exactly one consumer"
                 g = self._gsrc(y)
-                # ---- weight gradient
-                wg = capi.Wgrad()
-                wg.dtype = self.dtype
-                wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = x.B, x.H, x.W, x.C, y.H, y.W, y.C
-                wg.ks, wg.stride = kks, kstride
-                ctile = capi.lib().stl_wgrad_chunk(C.byref(wg))   # 32, or 64 for the wide-channel variant
-                want256 = os.environ.get("STLPOSE_WGRAD_TILE", "128") == "256"
-                if ctile == 64 and kks == 1:
-                    want256 = os.environ.get("STLPOSE_WGRAD_K1_TILE", "128") == "256"
-                big = (self.esz == 2 and kstride == 1 and want256
-                       and x.B * y.H * y.W >= 256 * 64 and (ctile == 32 or kks == 1))
-                if big:   # 256-pixel tiles: fewer barriers per pixel, but one block per CU
-                    wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32, maxpx=256,
-                                               maxhalo=352 if ctile == 64 else 384)
-                else:
-                    wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32,
-                                               maxhalo=192 if ctile == 64 else 576)
-                npt = math.ceil(x.B * (y.H + 1) / wg.TH) * math.ceil(y.W / wg.TW)
-                chunks = math.ceil(y.C / ctile) * math.ceil(x.C / ctile)
-                # Block budget per launch: one block per CU.  (End to end, budgets of 128..256 measure the
-                # same within run-to-run noise on MI355X: fewer blocks mean fewer slab bytes but a longer
-                # launch; 256 keeps the launch itself fastest.)
-                budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS", "256"))
-                if ctile == 64:
-                    budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS64", "512"))
-                elif kks == 1 and self.esz == 2:
-                    budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS_K1", str(budget)))
-                top = max(1, min(npt, budget // chunks if chunks <= budget else 1))
-                wg.nsplit = min(range(1, top + 1), key=lambda ns: (math.ceil(npt / ns) + 0.004 * ns * chunks / 8, ns))
-                wg.h = self._src(x)
-                wg.g = g
-                nel = y.C * kks * kks * x.C
-                part_off = self._slab_elems
-                self._slab_elems += (wg.nsplit * nel + 3) // 4 * 4
-                self.slabs.append(dict(part_off=part_off, grad_off=ci.master_off, nsplit=wg.nsplit, Co=ci.Co, Ci=ci.Ci,
-                                       ks=ci.ks, Cip=ci.Cik, patch=int(ci.patch), stride=0, struct=wg))
-                # weight gradients are off the critical path (only the data-gradient chain is): give
-                # them their own streams so they overlap with the chain
                 wstrm = (self.nstreams + strm % self.nwstreams) if self.wgrad_streams else strm
-                ops.append(("stl_conv_wgrad", wg, wstrm, [y.dt.data_ptr(), x.ptr], [id(wg)]))
-                bk["reads"].append(id(wg))
-                bk["strm"] = wstrm
+                # Fused backward (conv_core.hip, NCO > 0): the two-conv units' 3x3 stride-1 C -> C convolutions with
+                # C = 32 / 64 -- the bandwidth-bound half of the network -- compute the weight gradient inside the
+                # data-gradient launch: dt and y are fetched once for both, one launch instead of two.
+                fuse_wg = (fused_bwd and kks == 3 and kstride == 1 and x.needs_grad and x.C == y.C and x.C % 32 == 0
+                           and x.C <= 64 and x.H == y.H and x.W == y.W)
+                if not fuse_wg:
+                    self._emit_wgrad(ops, bk, x, y, ci, g, kks, kstride, strm, wstrm)
                 bucket_add(ci.master_off, ci.Co * ci.Ci * ci.ks * ci.ks)
                 bucket_add(y.bn.param_off, 2 * y.bn.C)   # gamma, beta of the BatchNorm behind this conv
                 # ---- data gradient
@@ -481,10 +448,28 @@ class Engine:
                 d.Ho, d.Wo, d.Co = x.H, x.W, x.C
                 d.ks, d.stride, d.stuff = kks, 1, int(kstride == 2)
                 d.TH, d.TW, d.shape = 0, 0, -1
+                if fuse_wg:
+                    d.partial = 1   # plan for the fused block shape; the slab pointer is patched in below
                 capi.call("stl_conv_plan", C.byref(d))
                 d.src = g
                 d.w = self.wk.data_ptr() + ci.bwd_off * self.esz
                 dreads = [y.dt.data_ptr()]
+                dwrites = []
+                if fuse_wg:
+                    nslab = x.C // 32
+                    blocks = int(os.environ.get("STLPOSE_FUSED_BLOCKS", "512"))
+                    npt = math.ceil(x.B * (x.H + 1) / d.TH) * math.ceil(x.W / d.TW)
+                    d.wg_nsplit = max(8, min(blocks // nslab, math.ceil(npt / 8) * 8) // 8 * 8)
+                    d.wg_h = self._src(x)
+                    nel = y.C * 9 * x.C
+                    part_off = self._slab_elems
+                    self._slab_elems += (d.wg_nsplit * nel + 3) // 4 * 4
+                    self.slabs.append(dict(part_off=part_off, grad_off=ci.master_off, nsplit=d.wg_nsplit, Co=ci.Co, Ci=ci.Ci,
+                                           ks=ci.ks, Cip=ci.Cik, patch=int(ci.patch), stride=0, struct=d))
+                    dreads.append(x.ptr)
+                    dwrites.append(id(d))
+                    bk["reads"].append(id(d))
+                    bk["strm"] = wstrm
                 if x.kind == "plain":
                     out = self._new_grad(x)
                     if x.grads:
@@ -515,7 +500,7 @@ class Engine:
                     d.mask_bn = self._src(x)
                     d.red = self.rstats.data_ptr() + 8 * x.bn.stats_off
                 d.out = out.data_ptr()
-                ops.append(("stl_conv_forward", d, strm, dreads, [out.data_ptr()]))
+                ops.append(("stl_conv_forward", d, strm, dreads, [out.data_ptr()] + dwrites))
         bucket_close(force=True)
         assert bk["done"] == 0 and bk["hi"] == 0, "gradient buckets do not cover the parameter buffer"
         # slab arena + reduce table
@@ -548,6 +533,48 @@ class Engine:
             br.rstats, br.grads = self.rstats.data_ptr(), st.grads.data_ptr()
             br.tab, br.n = self._bn_tab.data_ptr() + i0 * C.sizeof(capi.BNRec), i1 - i0
         self.bwd_ops = ops
+
+    def _emit_wgrad(self, ops, bk, x: Act, y: Act, ci: ConvInfo, g, kks: int, kstride: int, strm: int, wstrm: int):
+        """Stand-alone weight-gradient launch of one convolution (split-K slabs) on its own stream: weight
+        gradients are off the critical path (only the data-gradient chain is), so they overlap with the chain."""
+        wg = capi.Wgrad()
+        wg.dtype = self.dtype
+        wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = x.B, x.H, x.W, x.C, y.H, y.W, y.C
+        wg.ks, wg.stride = kks, kstride
+        ctile = capi.lib().stl_wgrad_chunk(C.byref(wg))   # 32, or 64 for the wide-channel variant
+        want256 = os.environ.get("STLPOSE_WGRAD_TILE", "128") == "256"
+        if ctile == 64 and kks == 1:
+            want256 = os.environ.get("STLPOSE_WGRAD_K1_TILE", "128") == "256"
+        big = (self.esz == 2 and kstride == 1 and want256
+               and x.B * y.H * y.W >= 256 * 64 and (ctile == 32 or kks == 1))
+        if big:   # 256-pixel tiles: fewer barriers per pixel, but one block per CU
+            wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32, maxpx=256,
+                                       maxhalo=352 if ctile == 64 else 384)
+        else:
+            wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32,
+                                       maxhalo=192 if ctile == 64 else 576)
+        npt = math.ceil(x.B * (y.H + 1) / wg.TH) * math.ceil(y.W / wg.TW)
+        chunks = math.ceil(y.C / ctile) * math.ceil(x.C / ctile)
+        # Block budget per launch: one block per CU.  (End to end, budgets of 128..256 measure the
+        # same within run-to-run noise on MI355X: fewer blocks mean fewer slab bytes but a longer
+        # launch; 256 keeps the launch itself fastest.)
+        budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS", "256"))
+        if ctile == 64:
+            budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS64", "512"))
+        elif kks == 1 and self.esz == 2:
+            budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS_K1", str(budget)))
+        top = max(1, min(npt, budget // chunks if chunks <= budget else 1))
+        wg.nsplit = min(range(1, top + 1), key=lambda ns: (math.ceil(npt / ns) + 0.004 * ns * chunks / 8, ns))
+        wg.h = self._src(x)
+        wg.g = g
+        nel = y.C * kks * kks * x.C
+        part_off = self._slab_elems
+        self._slab_elems += (wg.nsplit * nel + 3) // 4 * 4
+        self.slabs.append(dict(part_off=part_off, grad_off=ci.master_off, nsplit=wg.nsplit, Co=ci.Co, Ci=ci.Ci,
+                               ks=ci.ks, Cip=ci.Cik, patch=int(ci.patch), stride=0, struct=wg))
+        ops.append(("stl_conv_wgrad", wg, wstrm, [y.dt.data_ptr(), x.ptr], [id(wg)]))
+        bk["reads"].append(id(wg))
+        bk["strm"] = wstrm
 
     def _build_tables(self):
         tab = (capi.BNRec * len(self.bns))()

@@ -222,6 +222,31 @@ def test_conv_bn_relu_chain_forward_backward(case, dt, wtile, monkeypatch):
     dx0 = (g1.detach().double() * rstd1) * (dxk - r[0] / n - xhat * r[1] / n)
     ref = x0r.grad.permute(0, 2, 3, 1).reshape(-1, Ci).double()
     assert relerr(dx0, ref) < tol * 3
+    # ---------------- fused backward (one launch: data gradient + weight gradient from the same staged tiles)
+    if ks == 3 and s == 1 and Ci == Co and Ci in (32, 64) and wtile == 128 and not wide:
+        nsp = 16
+        dx2 = torch.full((B * H * W * Ci,), float("nan"), device="cuda", dtype=td)
+        red2 = torch.zeros(capi.NSHARD * 2 * Ci, dtype=torch.float64, device="cuda")
+        part2 = torch.full((nsp * Co * 9 * Ci,), float("nan"), device="cuda")
+        f = capi.Conv()
+        f.shape = -1
+        f.dtype, f.B, f.Hi, f.Wi, f.Ci, f.Ho, f.Wo, f.Co = code, B, Ho, Wo, Co, H, W, Ci
+        f.ks, f.stride, f.stuff = 3, 1, 0
+        f.TH, f.TW = 0, 0
+        f.partial, f.wg_nsplit, f.wg_h = part2.data_ptr(), nsp, p.src
+        capi.call("stl_conv_plan", C.byref(f))
+        assert f.shape == 4
+        f.src, f.w, f.out = gs, wb.data_ptr(), dx2.data_ptr()
+        f.mask_y, f.mask_bn, f.red = x0t.data_ptr(), p.src, red2.data_ptr()
+        capi.call("stl_conv_forward", C.byref(f), stream())
+        torch.cuda.synchronize()
+        assert not torch.isnan(part2).any() and not torch.isnan(dx2.float()).any()
+        assert relerr(dx2.float(), dx.float()) < 1e-6          # same arithmetic as the stand-alone data gradient
+        r2 = red2.view(capi.NSHARD, 2, Ci).sum(0)
+        assert relerr(r2[0], r[0]) < 1e-5 and relerr(r2[1], r[1]) < 1e-5
+        dw2 = part2.view(nsp, Co, 9, Ci).sum(0).view(Co, 3, 3, Ci).permute(0, 3, 1, 2)
+        assert relerr(dw2, wr.grad) < tol * 3
+        assert relerr(dw2, dw) < (1e-5 if dt == "fp32" else 2e-3)   # vs the stand-alone weight gradient (other summation order)
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
