@@ -153,7 +153,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
         cs[c] = a, cs[k.cipad + c] = b, cs[2 * k.cipad + c] = cc;
     }
     if (p.mask_y) {
-        for (int c = tid; c < BCO; c += NTHR) {
+        // the LAST wave computes the mask constants while the first one(s) do the source's: the two sets are
+        // dependent global round trips each, and run in parallel on different waves instead of back to back
+        for (int c = tid - (NTHR - 64); c >= 0 && c < BCO; c += 64) {
             float a = 0.f, b = 0.f, mu = 0.f, rs = 0.f;
             if (n0 + c < p.Co) {
                 bn_mean_rstd(p.mask_bn, n0 + c, p.Co, mu, rs);
@@ -167,10 +169,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     float* hcs = reinterpret_cast<float*>(smem + k.off_ch);  // fused: [2][32] BN affine of the h slab
     char* sH = smem + k.off_h;
     if constexpr (FW) {
-        if (tid < 32) {
+        if (tid >= 64 && tid < 96) {   // wave 1 (see above)
+            const int c = tid - 64;
             float a = 1.f, b = 0.f, cc = 0.f;
-            if (p.wg_h.mode != STL_SRC_PLAIN) src_consts(p.wg_h, n0 + tid, p.Co, a, b, cc);
-            hcs[tid] = a, hcs[32 + tid] = b;
+            if (p.wg_h.mode != STL_SRC_PLAIN) src_consts(p.wg_h, n0 + c, p.Co, a, b, cc);
+            hcs[c] = a, hcs[32 + c] = b;
         }
         if (tid < PSA / 16) *reinterpret_cast<V16*>(sA + k.HP * PSA + tid * 16) = zero16();   // zero pixel row behind the halo tile
     }
@@ -386,14 +389,20 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
                 og[i] = in ? ((ty + 1) * k.HC + tx + 1) * PSA : k.HP * PSA;   // beyond the tile: the zero row
                 oh[i] = (ty * k.HC + tx) * k.psh;                             // tap (0, 0) corner of the pixel's 3x3 window
             }
+            // all fragment reads of the K step are issued back to back, the MFMAs follow behind counted waits
+            // (one read pair per MFMA with a full wait in between costs an LDS round trip per MFMA: 2 us per tile)
             const V16 af = cfrag_tr<T>(sA, og, acol, lane);
+            V16 bq[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int tap = CT == 2 ? j : 2 * j + w_hw;
-                if (tap < TAPS) {
-                    const V16 bf = cfrag_tr<T>(sH + ((tap / KS) * k.HC + (tap % KS)) * k.psh, oh, bcol, lane);
-                    mma16<T>(aw[j], af, bf);
-                }
+                const int tc = tap < TAPS ? tap : 0;
+                bq[j] = cfrag_tr<T>(sH + ((tc / KS) * k.HC + (tc % KS)) * k.psh, oh, bcol, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int tap = CT == 2 ? j : 2 * j + w_hw;
+                if (tap < TAPS) mma16<T>(aw[j], af, bq[j]);
             }
         }
     };

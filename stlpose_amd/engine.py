@@ -332,7 +332,11 @@ class Engine:
         self.dout = torch.zeros_like(self.out)
         producer = {id(n[2]): n for n in self.tape if n[0] == "fuse"}
         fuse_block_end = os.environ.get("STLPOSE_FUSE_BLOCK_END", "1") != "0"
-        fused_bwd = os.environ.get("STLPOSE_FUSED_BWD", "1") != "0"
+        # opt-in (STLPOSE_FUSED_BWD=1): measured on MI355X the fused launch is 36-38 us against 22 + 25 us for
+        # the two stand-alone launches and moves fewer bytes, but it puts the weight-gradient work on the
+        # data-gradient chain (the critical path) at two blocks per CU: 20.4 vs 19.7 ms per step
+        fused_bwd = os.environ.get("STLPOSE_FUSED_BWD", "0") != "0"
+        fused_c = os.environ.get("STLPOSE_FUSED_C", "32,64").split(",")
         # ---- gradient buckets: contiguous suffixes of the flat gradient buffer, closed as soon as every
         # parameter in them has its slabs / BatchNorm reductions complete (backward finishes the last
         # layers first).  Each bucket gets one ranged slab reduction + BN-gradient launch inside the
@@ -340,6 +344,12 @@ class Engine:
         self.buckets: List[dict] = []
         bucket_min = int(float(os.environ.get("STLPOSE_BUCKET_MB", "16")) * (1 << 20) / 4)
         bk = dict(done=0, lo=st.nparam, hi=st.nparam, slab0=0, reads=[], strm=0)
+        # The serial tail of backward (layer1 + stem: one branch, 113 MB tensors) finishes last.  Close a bucket
+        # where it begins, whatever its size, so that the final slab reduction (the only work left after the last
+        # weight gradient, in front of the optimiser) covers just the stem / layer1 slabs instead of every layer
+        # since the last 16 MB boundary.
+        tail_keys = [k for k in os.environ.get("STLPOSE_BUCKET_TAIL", "transition1.0.0.weight,layer1.1.conv1.weight").split(",") if k]
+        force_at = {st.param_off[k] for k in tail_keys if k in st.param_off}
 
         def bucket_add(off: int, size: int):
             bk["done"] += size
@@ -347,6 +357,7 @@ class Engine:
 
         def bucket_close(force: bool = False):
             complete = bk["done"] == bk["hi"] - bk["lo"]          # suffix [lo, hi) fully covered
+            force = force or (complete and bk["lo"] in force_at)
             if not complete or bk["done"] == 0 or (bk["done"] < bucket_min and not force):
                 return
             assert complete
@@ -434,7 +445,7 @@ class Engine:
                 # C = 32 / 64 -- the bandwidth-bound half of the network -- compute the weight gradient inside the
                 # data-gradient launch: dt and y are fetched once for both, one launch instead of two.
                 fuse_wg = (fused_bwd and kks == 3 and kstride == 1 and x.needs_grad and x.C == y.C and x.C % 32 == 0
-                           and x.C <= 64 and x.H == y.H and x.W == y.W)
+                           and x.C <= 64 and x.H == y.H and x.W == y.W and str(x.C) in fused_c)
                 if not fuse_wg:
                     self._emit_wgrad(ops, bk, x, y, ci, g, kks, kstride, strm, wstrm)
                 bucket_add(ci.master_off, ci.Co * ci.Ci * ci.ks * ci.ks)
@@ -532,7 +543,45 @@ class Engine:
             i0, i1 = bisect.bisect_left(bn_off, b["lo"]), bisect.bisect_left(bn_off, b["hi"])
             br.rstats, br.grads = self.rstats.data_ptr(), st.grads.data_ptr()
             br.tab, br.n = self._bn_tab.data_ptr() + i0 * C.sizeof(capi.BNRec), i1 - i0
-        self.bwd_ops = ops
+        self.bwd_ops = self._lag_wgrads(ops, int(os.environ.get("STLPOSE_WGRAD_LAG", "0")))
+        for b in self.buckets:   # bucket events are addressed by op index
+            b["op"] = next(i for i, o in enumerate(self.bwd_ops) if o[1] is b["br"])
+
+    @staticmethod
+    def _lag_wgrads(ops, lag: int):
+        """Issue every stand-alone weight gradient `lag` launches LATER than the reverse walk emits it.
+        A weight gradient is emitted right behind the data gradient that produces its input, i.e. while
+        that producer is still running; its event wait then parks at the head of a hardware queue that it
+        shares with another branch's data-gradient stream (8 streams -> 4 queues) and blocks that branch.
+        Issued a few launches later the wait is already satisfied when the packet reaches the queue head.
+        A weight gradient never moves past the slab reduction that reads it."""
+        if lag <= 0:
+            return ops
+        out, pending = [], []   # pending: [remaining, op]
+        for op in ops:
+            if op[0] == "stl_conv_wgrad":
+                pending.append([lag, op])
+                continue
+            if op[0] == "stl_reduce_slabs_range":   # its reads include the ids of the bucket's weight gradients
+                need = {r for r in op[3] if not isinstance(r, tuple)}
+                keep = []
+                for item in pending:
+                    if any(w in need for w in item[1][4]):
+                        out.append(item[1])
+                    else:
+                        keep.append(item)
+                pending = keep
+            out.append(op)
+            keep = []
+            for item in pending:
+                item[0] -= 1
+                if item[0] <= 0:
+                    out.append(item[1])
+                else:
+                    keep.append(item)
+            pending = keep
+        out += [item[1] for item in pending]
+        return out
 
     def _emit_wgrad(self, ops, bk, x: Act, y: Act, ci: ConvInfo, g, kks: int, kstride: int, strm: int, wstrm: int):
         """Stand-alone weight-gradient launch of one convolution (split-K slabs) on its own stream: weight

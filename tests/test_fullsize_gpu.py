@@ -108,3 +108,33 @@ def test_gradient_buckets_cover_the_flat_buffer_and_dp_path_matches(monkeypatch,
     assert torch.equal(g0, g1) and torch.equal(w0, w1)
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def test_fused_backward_matches_separate_launches_at_full_size(monkeypatch):
+    """The opt-in fused backward (STLPOSE_FUSED_BWD=1) against the default stand-alone launches on the benchmarked
+    plan (W32, 384x288, batch 32, bf16): the data gradients are the same arithmetic (bit-identical activations'
+    gradients -> identical BatchNorm gradients), the weight gradients differ only in split-K summation order."""
+    img, tgt, tw = _batch(32, 384, 288, seed=9)
+
+    def grads(fused):
+        monkeypatch.setenv("STLPOSE_FUSED_BWD", fused)
+        torch.manual_seed(21)
+        m = PoseHighResolutionNet("w32", "bf16").cuda()
+        ts = TrainStep(m, 32, 384, 288, optimizer="sgd", lr=0.0, momentum=0.0)
+        assert sum(1 for o in ts.eng.bwd_ops if o[0] == "stl_conv_forward" and o[1].partial) == (132 if fused == "1" else 0)
+        ts.load_batch(img.cuda(), tgt.cuda(), tw.cuda())
+        l = float(ts.step().item())
+        torch.cuda.synchronize()
+        return l, ts.store.grads.clone(), ts.store
+    l0, g0, st = grads("0")
+    l1, g1, _ = grads("1")
+    assert l0 == l1
+    worst = 0.0
+    for k, shape in st.reg.params:
+        a = st.param_off[k]
+        n = int(np.prod(shape)) if shape else 1
+        d = float((g0[a:a + n] - g1[a:a + n]).abs().max()) / (float(g0[a:a + n].abs().max()) + 1e-20)
+        worst = max(worst, d)
+        if len(shape) != 4:
+            assert d < 1e-5, (k, d)       # BatchNorm / bias gradients: reductions of identical tensors
+    assert worst < 2e-3, worst            # conv weights: same products, other fp32 summation order

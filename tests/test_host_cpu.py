@@ -67,10 +67,11 @@ def test_dropin_state_dict_abi(golden_dir):
     assert sum(p.numel() for p in PoseHighResolutionNet("w48").parameters()) == 63595745
 
 
-def test_planner_dry_run():
+def test_planner_dry_run(monkeypatch):
     """Plan construction needs no GPU: check op counts against SURVEY 8(a) (293 convs incl. head,
     28 upsample terms) and that every BN activation has a single consumer."""
     from collections import Counter
+    monkeypatch.setenv("STLPOSE_FUSED_BWD", "1")
     from stlpose_amd import PoseHighResolutionNet, capi
     from stlpose_amd.engine import Engine
     m = PoseHighResolutionNet("w32", "bf16")
@@ -84,6 +85,9 @@ def test_planner_dry_run():
     assert fused == 132 and b["stl_conv_wgrad"] == 292 - fused
     assert b["stl_conv_forward"] == 291 and b["stl_upsample_backward"] == 28
     assert len(e.slabs) == 292 + 2   # + head weight and bias
+    monkeypatch.setenv("STLPOSE_FUSED_BWD", "0")
+    e0 = Engine(m.arch, m._store, 2, 256, 192, capi.BF16, True)
+    assert Counter(o[0] for o in e0.bwd_ops)["stl_conv_wgrad"] == 292
     assert len(e.bns) == 292 and e.out.shape == (2, 17, 64, 48)
     ev = Engine(m.arch, m._store, 1, 64, 64, capi.F32, False)
     assert not ev.bwd_ops
