@@ -67,7 +67,8 @@ def time_dominant_kernel(ts):
     tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
     flops = sum(2.0 * d.B * d.Ho * d.Wo * d.Co * d.Ci * 9 for _, _, d in evs)
     esz = 2 if eng.dtype == capi.BF16 else 4
-    bytes_alg = sum((d.B * d.Hi * d.Wi * d.Ci + 2 * d.B * d.Ho * d.Wo * d.Co) * esz + d.nsplit * d.Co * d.Ci * 9 * 4 for _, _, d in evs)
+    # h, dt and y read once, dw written once (split-K slabs are NOT algorithmic bytes)
+    bytes_alg = sum((d.B * d.Hi * d.Wi * d.Ci + 2 * d.B * d.Ho * d.Wo * d.Co) * esz + d.Co * d.Ci * 9 * 4 for _, _, d in evs)
     return dict(kernel="wgrad_kernel<bf16,KS=3,GQ=1,TPX=128|256> (3x3 stride-1 weight gradient, BN-backward on load)",
                 launches=len(evs), ms=tot_ms / len(evs), tflops=flops / tot_ms / 1e9, gbs=bytes_alg / tot_ms / 1e6)
 
@@ -97,6 +98,98 @@ def cpu_baseline(arch, H, W, seconds=20.0):
     med = float(np.median(times[1:])) if len(times) > 1 else times[0]
     return dict(value=B / med, unit="images/sec", cores=torch.get_num_threads(), kind="port",
                 sample=f"oracle RefPoseNet({arch}) fp32 {H}x{W} bs{B} fwd+MSE+bwd+Adam, median of {max(len(times) - 1, 1)} steps")
+
+
+def cpu_baseline_cfg1(seconds=8.0):
+    """BASELINE configs[0] exactly (W32, 256x192, bs 2, fwd + MSE + bwd; Adam timed separately) on all the host
+    cores this process may use and on 8 threads (the build container's count)."""
+    from oracle import hrnet_ref, pose_ref
+    out = {}
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for n in sorted({min(ncpu, 64), 8}, reverse=True):
+        torch.set_num_threads(n)
+        torch.manual_seed(0)
+        m = hrnet_ref.RefPoseNet("w32").train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        img, tgt, tw = torch.randn(2, 3, 256, 192), torch.rand(2, 17, 64, 48), torch.ones(2, 17, 1)
+        fb, ad = [], []
+        t_end = time.time() + seconds / 2
+        while time.time() < t_end or len(fb) < 3:
+            t0 = time.time()
+            opt.zero_grad()
+            pose_ref.person_mse_loss(m(img), tgt, tw).backward()
+            t1 = time.time()
+            opt.step()
+            fb.append(t1 - t0), ad.append(time.time() - t1)
+            if len(fb) >= 12:
+                break
+        out[f"threads_{n}"] = dict(images_per_sec_fwd_bwd=round(2 / float(np.median(fb[1:])), 2),
+                                   adam_step_ms=round(1e3 * float(np.median(ad[1:])), 1), steps=len(fb) - 1)
+    out["host_cpus"] = ncpu
+    return out
+
+
+def extra_fp32_path(arch, batch, H, W, dev, steps=6, warmup=2):
+    """The parity path (fp32 storage, fp32-input MFMA at 157 TFLOP/s peak) at the same configuration."""
+    from stlpose_amd import PoseHighResolutionNet
+    from stlpose_amd.train_step import TrainStep
+    torch.manual_seed(0)
+    model = PoseHighResolutionNet(arch, "fp32").to(dev)
+    ts = TrainStep(model, batch, H, W, optimizer="adam", lr=1e-3, device=dev)
+    ts.load_batch(*synth_batch(batch, H, W, 0, dev, sigma=3.0 if H >= 384 else 2.0))
+    for _ in range(warmup):
+        ts.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ts.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    fl = FLOPS_PER_IMG.get((arch, H, W))
+    tf = batch / dt * fl / 1e12 if fl else None
+    del ts, model
+    torch.cuda.empty_cache()
+    return dict(metric=f"images/sec/GPU HRNet-{arch.upper()} {H}x{W} train step, fp32 parity path", value=round(batch / dt, 2),
+                unit="images/sec", ms_per_step=round(dt * 1e3, 3), dtype="f32",
+                roofline=dict(bound="mfma", achieved=round(tf, 2) if tf else None, peak=157.3, unit="TFLOP/s",
+                              frac=round(tf / 157.3, 4) if tf else None, traffic=None,
+                              note="whole step against the fp32-input MFMA peak (v_mfma_f32_16x16x4_f32)"))
+
+
+def extra_vgg_cfg4(dev, reps=5):
+    """BASELINE configs[3] as far as the reference defines it (V1): VGG16 perceptual loss forward, batch 16,
+    3 x 512 x 512, fp32, resize=False = 2 x 16 images through features[:23] (145.9 GFLOP per image and pass)."""
+    from oracle import vgg_ref
+    from stlpose_amd import VGGPerceptualLoss
+    w = vgg_ref.synth_vgg_weights()
+    g = torch.Generator().manual_seed(16)
+    a = torch.rand(16, 3, 512, 512, generator=g)
+    b = (a + 0.2 * torch.randn(16, 3, 512, 512, generator=g)).clamp_(0, 1)
+    res = {}
+    for dt_name, peak in (("fp32", 157.3), ("bf16", MFMA_PEAK_BF16)):
+        m = VGGPerceptualLoss(resize=False, state_dict=w, compute_dtype=dt_name).to(dev)
+        ad, bd = a.to(dev), b.to(dev)
+        for _ in range(2):
+            m(ad, bd)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            loss = m(ad, bd)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        tf = 2 * 16 * 145.9e9 / dt / 1e12
+        res[dt_name] = dict(ms_per_loss=round(dt * 1e3, 3), pairs_per_sec=round(16 / dt, 2), loss=float(loss.item()),
+                            roofline=dict(bound="mfma", achieved=round(tf, 2), peak=peak, unit="TFLOP/s", frac=round(tf / peak, 4), traffic=None))
+        del m
+    # CPU baseline: the oracle on 2 pairs (bounded sample of the same workload)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    t0 = time.time()
+    with torch.no_grad():
+        vgg_ref.vgg_perceptual_loss(a[:2], b[:2], w, resize=False)
+    cpu = 2 / (time.time() - t0)
+    return dict(metric="image pairs/sec VGG16 perceptual loss forward 512x512 bs=16 (V1 of cfg4)", unit="pairs/sec", **res,
+                cpu_baseline=dict(value=round(cpu, 3), unit="pairs/sec", cores=torch.get_num_threads(), kind="port",
+                                  sample="oracle.vgg_ref fp32, 2 pairs of 3x512x512, resize=False, one evaluation"))
 
 
 def main():
@@ -190,7 +283,8 @@ def main():
             for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_wgrad.json"))):
                 try:
                     rec = json.load(open(f))
-                    if rec.get("launches") == dom["launches"] and (a.arch, a.height, a.width, a.batch, a.dtype) == ("w32", 384, 288, 32, "bf16"):
+                    if rec.get("launches") == dom["launches"] and (a.arch, a.height, a.width, a.batch, a.dtype) == ("w32", 384, 288, 32, "bf16") \
+                            and rec.get("fused_bwd", "0") == os.environ.get("STLPOSE_FUSED_BWD", "0"):
                         traffic = round(rec["traffic_bytes_per_launch"])
                 except Exception:
                     pass
@@ -210,8 +304,21 @@ def main():
                    step_tflops=round(value * flops_img / 1e12, 2) if flops_img else None,
                    step_mfma_frac=round(value / world * flops_img / 1e12 / MFMA_PEAK_BF16, 4) if flops_img else None,
                    roofline=roof)
+        if world == 1 and not a.no_extras:
+            del ts, model
+            torch.cuda.empty_cache()
+            extras = {}
+            for name, fn in (("fp32_path", lambda: extra_fp32_path(a.arch, a.batch, a.height, a.width, dev)),
+                             ("vgg_cfg4", lambda: extra_vgg_cfg4(dev))):
+                try:
+                    extras[name] = fn()
+                except Exception as e:   # an extra leg must never take the headline line down
+                    extras[name] = dict(error=f"{type(e).__name__}: {e}")
+            out["extras"] = extras
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.arch, a.height, a.width)
+            if not a.no_extras:
+                out["cpu_baseline"]["cfg1"] = cpu_baseline_cfg1()
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
