@@ -106,7 +106,7 @@ def cpu_baseline_cfg1(seconds=8.0):
     from oracle import hrnet_ref, pose_ref
     out = {}
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    for n in sorted({min(ncpu, 64), 8}, reverse=True):
+    for n in sorted({min(ncpu, 16), 8}, reverse=True):   # 16 = the GPU box's CPU share for one GPU
         torch.set_num_threads(n)
         torch.manual_seed(0)
         m = hrnet_ref.RefPoseNet("w32").train()

@@ -241,6 +241,15 @@ int stl_adam_slice(float* p, const float* g, float* m, float* v, int64_t n, cons
 int stl_sgd_slice(float* p, const float* g, float* mom, int64_t n, const float* hyper, const int32_t* step,
                   void* stream);
 
+/* Device affine crop + normalisation of a batch (reference data/JointsDataset.py:189-200: cv2.warpAffine(img,
+ * get_affine_transform(c, s, r, image_size), INTER_LINEAR) followed by ToTensor + Normalize, data_loaders.py:59-61).
+ * src: uint8 HWC RGB images packed in one buffer (src_off[b] bytes, src_hw[b] = (H, W)); minv[b] = the 2x3 matrix
+ * that maps OUTPUT pixel (x, y) to source coordinates (the inverse of the reference's `trans`); flip[b] != 0 reads the
+ * source mirrored left-right (the flip augmentation, :183-186); out = fp32 NCHW [B,3,Ho,Wo]; mean3/std3 may be NULL.
+ * Bilinear taps outside the source contribute 0 (BORDER_CONSTANT).  cv2's 1/32-pixel fixed-point coordinate rounding
+ * is NOT reproduced (exact float bilinear): parity for that rounding is unpinned (cv2 absent). */
+int stl_affine_crop(const uint8_t* src, const int64_t* src_off, const int32_t* src_hw, const float* minv, const int32_t* flip,
+                    float* out, int B, int Ho, int Wo, const float* mean3, const float* std3, void* stream);
 /* VGG perceptual path (reference lib/loss.py:17-58). */
 int stl_maxpool2x2(int dtype, const void* x, void* out, int B, int H, int W, int C, void* stream);
 int stl_l1_partial(int dtype, const void* a, const void* b, int64_t n, double* partial, int nblk,

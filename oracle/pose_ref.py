@@ -194,3 +194,32 @@ def oks_nms(kpts: np.ndarray, scores: np.ndarray, areas: np.ndarray, thresh: flo
         ovr = oks_iou(kpts[i], kpts[order[1:]], areas[i], areas[order[1:]])
         order = order[np.where(ovr <= thresh)[0] + 1]
     return keep
+
+
+def warp_affine_bilinear(img: np.ndarray, trans: np.ndarray, out_wh, flip: bool = False) -> np.ndarray:
+    """Float restatement of ``cv2.warpAffine(img, trans, (W, H), flags=cv2.INTER_LINEAR)`` as the reference calls
+    it (data/JointsDataset.py:190-195): dst(x, y) = bilinear sample of src at trans^-1 (x, y, 1), pixel centres at
+    integer coordinates, constant zero border (taps outside the image contribute 0).  cv2 itself is a third-party
+    dependency absent from this image (opencv-python pinned in environment.yml); its 1/32-pixel fixed-point
+    coordinate rounding is NOT restated -> PARITY UNPINNED for that rounding (differences <= 1/64 px of
+    interpolation).  ``flip`` mirrors the source first (JointsDataset.py:184).  img uint8 HWC -> float HWC in 0..255."""
+    if flip:
+        img = img[:, ::-1, :]
+    h, w = img.shape[:2]
+    wo, ho = int(out_wh[0]), int(out_wh[1])
+    minv = np.linalg.inv(np.concatenate([np.asarray(trans, np.float64), [[0.0, 0.0, 1.0]]], 0))[:2].astype(np.float32)
+    ys, xs = np.mgrid[0:ho, 0:wo].astype(np.float32)
+    sx = minv[0, 0] * xs + minv[0, 1] * ys + minv[0, 2]
+    sy = minv[1, 0] * xs + minv[1, 1] * ys + minv[1, 2]
+    x0, y0 = np.floor(sx), np.floor(sy)
+    ax, ay = sx - x0, sy - y0
+    out = np.zeros((ho, wo, 3), np.float32)
+    src = img.astype(np.float32)
+    for dy in (0, 1):
+        for dx in (0, 1):
+            xx, yy = (x0 + dx).astype(np.int64), (y0 + dy).astype(np.int64)
+            ok = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h)
+            wgt = (ax if dx else 1 - ax) * (ay if dy else 1 - ay)
+            v = src[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)]
+            out += np.where(ok, wgt, 0.0)[..., None] * v
+    return out

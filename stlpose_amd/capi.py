@@ -131,6 +131,7 @@ SIGNATURES = {
     "stl_bn_param_grads": [vp, vp, vp, i32, vp],
     "stl_adam_step": [vp, vp, vp, vp, i64, vp, vp, vp],
     "stl_sgd_step": [vp, vp, vp, i64, vp, vp, vp],
+    "stl_affine_crop": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp],
     "stl_maxpool2x2": [i32, vp, vp, i32, i32, i32, i32, vp],
     "stl_l1_partial": [i32, vp, vp, i64, vp, i32, vp],
     "stl_bilinear_nchw": [vp, vp, i32, i32, i32, i32, i32, i32, vp],

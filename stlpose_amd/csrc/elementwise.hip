@@ -659,6 +659,47 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, floa
     }
 }
 
+
+// ---------------------------------------------------------------- affine crop (data/JointsDataset.py:189-200)
+// out[b, c, y, x] = (bilinear(src_b, Minv_b * (x, y, 1)) / 255 - mean[c]) / std[c]; taps outside the source image
+// contribute 0 (cv2.warpAffine's default BORDER_CONSTANT); flip: the source is read mirrored left-right
+// (data_numpy[:, ::-1, :]).  Source images are uint8 HWC (RGB) packed in one buffer.
+__global__ __launch_bounds__(256) void affine_crop_kernel(const uint8_t* src, const int64_t* src_off, const int32_t* src_hw,
+                                                          const float* minv, const int32_t* flip, float* out, int Ho, int Wo,
+                                                          const float* mean3, const float* std3) {
+    const int b = blockIdx.y;
+    const int H = src_hw[2 * b], W = src_hw[2 * b + 1];
+    const uint8_t* img = src + src_off[b];
+    const float m0 = minv[6 * b], m1 = minv[6 * b + 1], m2 = minv[6 * b + 2];
+    const float m3 = minv[6 * b + 3], m4 = minv[6 * b + 4], m5 = minv[6 * b + 5];
+    const bool fl = flip && flip[b];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < Ho * Wo; i += gridDim.x * 256) {
+        const int y = i / Wo, x = i - y * Wo;
+        const float sx = m0 * x + m1 * y + m2, sy = m3 * x + m4 * y + m5;
+        const float fx = floorf(sx), fy = floorf(sy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float ax = sx - fx, ay = sy - fy;
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int xx = x0 + dx, yy = y0 + dy;
+                if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
+                    const float w = (dx ? ax : 1.f - ax) * (dy ? ay : 1.f - ay);
+                    const uint8_t* px = img + ((size_t)yy * W + (fl ? W - 1 - xx : xx)) * 3;
+                    acc[0] += w * px[0], acc[1] += w * px[1], acc[2] += w * px[2];
+                }
+            }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = acc[c] * (1.f / 255.f);
+            if (mean3) v = (v - mean3[c]) / std3[c];
+            out[(((size_t)b * 3 + c) * Ho + y) * Wo + x] = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- VGG helpers
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_kernel(const void* x, void* out, int B, int H, int W, int C) {
@@ -1104,6 +1145,17 @@ extern "C" int stl_gaussian_targets(const float* joints_xy, const float* vis, fl
     hipLaunchKernelGGL(gaussian_targets_kernel, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, joints_xy, vis, target, tweight,
                        B * J, Hh, Wh, (double)stride_x, (double)stride_y, sigma);
     STL_LAUNCH_CHECK("gaussian_targets");
+    return 0;
+}
+
+extern "C" int stl_affine_crop(const uint8_t* src, const int64_t* src_off, const int32_t* src_hw, const float* minv, const int32_t* flip,
+                               float* out, int B, int Ho, int Wo, const float* mean3, const float* std3, void* stream) {
+    if (B == 0) return 0;
+    STL_CHECK(src && src_off && src_hw && minv && out && Ho > 0 && Wo > 0, "affine_crop: bad arguments");
+    STL_CHECK((mean3 == nullptr) == (std3 == nullptr), "affine_crop: mean and std go together");
+    const int gx = (Ho * Wo + 255) / 256;
+    hipLaunchKernelGGL(affine_crop_kernel, dim3(gx < 64 ? gx : 64, B), dim3(256), 0, ST, src, src_off, src_hw, minv, flip, out, Ho, Wo, mean3, std3);
+    STL_LAUNCH_CHECK("affine_crop");
     return 0;
 }
 

@@ -472,8 +472,52 @@ def gen_g12():
     print("G12 avg_acc", avg, "cnt", cnt, "kept per image", [len(g) for g in kept])
 
 
+def gen_g11():
+    """G11: the reference's transform arithmetic for the crop / flip augmentation (lib/transforms.py:167-250):
+    get_affine_transform (cv2.getAffineTransform replaced by the exact 3-point solve, as in main()),
+    affine_transform and fliplr_joints on seeded persons -- forward and inverse matrices, transformed joints."""
+    tmp = tempfile.mkdtemp(prefix="stl_golden_")
+    if "CONFIG" not in sys.modules:
+        _install_shims(tmp)
+    import lib.transforms as ref_tf
+
+    def _get_affine(src, dst):
+        a = np.concatenate([np.asarray(src, np.float64), np.ones((3, 1))], 1)
+        return np.linalg.solve(a, np.asarray(dst, np.float64)).T
+    sys.modules["cv2"].getAffineTransform = _get_affine
+    rng = np.random.Generator(np.random.PCG64(1111))
+    n = 8
+    centers = rng.uniform(40, 400, (n, 2))
+    scales = rng.uniform(0.4, 2.5, (n, 2))
+    rots = np.array([0.0, 0.0, 30.0, -45.0, 80.0, -12.5, 0.0, 61.0])
+    sizes = [(192, 256), (288, 384)]
+    pairs = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]
+    fx = dict(centers=centers, scales=scales, rots=rots, sizes=np.array(sizes))
+    for si, size in enumerate(sizes):
+        tf, ti = [], []
+        for i in range(n):
+            tf.append(ref_tf.get_affine_transform(centers[i], scales[i], rots[i], size))
+            ti.append(ref_tf.get_affine_transform(centers[i], scales[i], rots[i], size, inv=1))
+        fx[f"trans_{si}"], fx[f"trans_inv_{si}"] = np.stack(tf), np.stack(ti)
+    joints = np.zeros((n, 17, 3))
+    joints[..., :2] = rng.uniform(0, 480, (n, 17, 2))
+    vis = np.zeros((n, 17, 3))
+    vis[..., 0] = vis[..., 1] = rng.uniform(size=(n, 17)) < 0.8
+    widths = rng.integers(300, 640, n)
+    fj, fv, tj = [], [], []
+    for i in range(n):
+        j, v = ref_tf.fliplr_joints(joints[i].copy(), vis[i].copy(), int(widths[i]), pairs)
+        fj.append(j), fv.append(v)
+        t = fx["trans_1"][i]
+        tj.append(np.stack([ref_tf.affine_transform(joints[i, k, 0:2], t) for k in range(17)]))
+    fx.update(joints=joints, joints_vis=vis, widths=widths, flipped_joints=np.stack(fj), flipped_vis=np.stack(fv),
+              transformed_joints=np.stack(tj))
+    np.savez_compressed(os.path.join(HERE, "g11_affine.npz"), **fx)
+    print("G11 done", fx["trans_0"][2])
+
+
 if __name__ == "__main__":
-    extra = dict(g9=gen_g9, g8train=gen_g8_train, g10=gen_g10, g12=gen_g12)
+    extra = dict(g9=gen_g9, g8train=gen_g8_train, g10=gen_g10, g11=gen_g11, g12=gen_g12)
     if len(sys.argv) > 1 and sys.argv[1] in extra:
         extra[sys.argv[1]]()
     else:
