@@ -146,37 +146,42 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     char* sA = smem + k.off_a;
     char* sB = smem + k.off_b;
 
-    // ---- per-channel constants
-    for (int c = tid; c < k.cipad; c += NTHR) {
-        float a = 0.f, b = 0.f, cc = 0.f;
-        if (c < p.Ci) src_consts(p.src, c, p.Ci, a, b, cc);
-        cs[c] = a, cs[k.cipad + c] = b, cs[2 * k.cipad + c] = cc;
-    }
-    if (p.mask_y) {
-        // the LAST wave computes the mask constants while the first one(s) do the source's: the two sets are
-        // dependent global round trips each, and run in parallel on different waves instead of back to back
-        for (int c = tid - (NTHR - 64); c >= 0 && c < BCO; c += 64) {
-            float a = 0.f, b = 0.f, mu = 0.f, rs = 0.f;
-            if (n0 + c < p.Co) {
-                bn_mean_rstd(p.mask_bn, n0 + c, p.Co, mu, rs);
-                a = p.mask_bn.gamma[n0 + c] * rs;
-                b = p.mask_bn.beta[n0 + c] - mu * a;
-            }
-            cm[c] = a, cm[BCO + c] = b, cm[2 * BCO + c] = mu, cm[3 * BCO + c] = rs;
-        }
-    }
-
+    // ---- per-channel constants.  (Computing them AFTER the first tile's loads have been issued, so that the
+    // statistics round trip overlaps the tile's, measured SLOWER: 19.2 -> 23.1 us for the 96x72 C=32 layer --
+    // hipcc sinks the tile loads below the constants code, sched_barrier or not.)
     float* hcs = reinterpret_cast<float*>(smem + k.off_ch);  // fused: [2][32] BN affine of the h slab
     char* sH = smem + k.off_h;
-    if constexpr (FW) {
-        if (tid >= 64 && tid < 96) {   // wave 1 (see above)
-            const int c = tid - 64;
-            float a = 1.f, b = 0.f, cc = 0.f;
-            if (p.wg_h.mode != STL_SRC_PLAIN) src_consts(p.wg_h, n0 + c, p.Co, a, b, cc);
-            hcs[c] = a, hcs[32 + c] = b;
+    auto compute_consts = [&]() {
+        for (int c = tid; c < k.cipad; c += NTHR) {
+            float a = 0.f, b = 0.f, cc = 0.f;
+            if (c < p.Ci) src_consts(p.src, c, p.Ci, a, b, cc);
+            cs[c] = a, cs[k.cipad + c] = b, cs[2 * k.cipad + c] = cc;
         }
-        if (tid < PSA / 16) *reinterpret_cast<V16*>(sA + k.HP * PSA + tid * 16) = zero16();   // zero pixel row behind the halo tile
-    }
+        if (p.mask_y) {
+            // the LAST wave computes the mask constants while the first one(s) do the source's: the two sets are
+            // dependent global round trips each, and run in parallel on different waves instead of back to back
+            for (int c = tid - (NTHR - 64); c >= 0 && c < BCO; c += 64) {
+                float a = 0.f, b = 0.f, mu = 0.f, rs = 0.f;
+                if (n0 + c < p.Co) {
+                    bn_mean_rstd(p.mask_bn, n0 + c, p.Co, mu, rs);
+                    a = p.mask_bn.gamma[n0 + c] * rs;
+                    b = p.mask_bn.beta[n0 + c] - mu * a;
+                }
+                cm[c] = a, cm[BCO + c] = b, cm[2 * BCO + c] = mu, cm[3 * BCO + c] = rs;
+            }
+        }
+
+        if constexpr (FW) {
+            if (tid >= 64 && tid < 96) {   // wave 1 (see above)
+                const int c = tid - 64;
+                float a = 1.f, b = 0.f, cc = 0.f;
+                if (p.wg_h.mode != STL_SRC_PLAIN) src_consts(p.wg_h, n0 + c, p.Co, a, b, cc);
+                hcs[c] = a, hcs[32 + c] = b;
+            }
+            if (tid < PSA / 16) *reinterpret_cast<V16*>(sA + k.HP * PSA + tid * 16) = zero16();   // zero pixel row behind the halo tile
+        }
+    };
+    compute_consts();
     STAMP(1);
     // ---- loop-invariant per-thread descriptors
     int a_rc[NVA];  // (halo row << 16) | halo col, -1 when this slot is unused
@@ -817,7 +822,9 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     // The budget is for the whole grid (pixel blocks x channel blocks): one resident round of blocks
     // (256 for the 8-wave shapes, 1024 for the 4-wave ones); with ny channel blocks per pixel tile the
     // pixel dimension gets budget / ny (3x3 32->256 at 96x72: 102 -> 90 us; tools/conv_probe8.py)
-    int cap = sh.ws ? 256 : (sh.thr == 512 ? 256 : 1024);
+    static const int cap4 = getenv("STL_CONV_GRID_CAP4") ? atoi(getenv("STL_CONV_GRID_CAP4")) : 1024;
+    static const int cap8 = getenv("STL_CONV_GRID_CAP8") ? atoi(getenv("STL_CONV_GRID_CAP8")) : 256;
+    int cap = sh.ws ? 256 : (sh.thr == 512 ? cap8 : cap4);
     if (!getenv("STL_CONV_CAP_PER_TILE")) cap = std::max(8, (cap / k.ny + 7) / 8 * 8);
     if (const char* e = getenv("STL_CONV_GRID_CAP")) cap = atoi(e) > 0 ? (atoi(e) + 7) / 8 * 8 : cap;
     if (gx > cap) gx = cap;

@@ -28,6 +28,8 @@ struct WgK {
     int tiles_c, npt, HR, HC, HP, PI, pad, taps;
     int psg, psh;  // LDS bytes per pixel (32 channels + 16 B pad)
     int off_cg, off_ch, off_g, off_h;
+    int grp_stride;  // NG = 2: byte distance between the two wave groups' LDS tiles
+    int quad;        // NG = 1: cross-wave reduction quadrant by quadrant (small LDS footprint)
     float r_TW, r_HC, r_tc, r_vp, r_PI;  // reciprocals for fdiv
 };
 
@@ -61,8 +63,13 @@ __device__ __forceinline__ V16 frag_tr<float>(const char* base, const int* rowof
 
 // NVH: h (input halo) staging vectors per thread; GQ: g is BNBWD (second tensor on load)
 // OCC: blocks per CU the register budget is sized for (2 only where it does not spill)
-template <typename T, int KS, int NVH, bool GQ, int TPX, int OCC>
-__global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgK k) {
+// NG: wave groups per block.  NG = 2: two groups of 4 waves, each with its OWN LDS tiles and its own tile sequence
+// (tile 2i + group of the block), under block-wide barriers.  The K loop of a group is a chain of memory round
+// trips (load -> transform -> LDS -> barrier -> 36 MFMAs), ~2 us per 128 pixels for 0.3 us of matrix work; two
+// groups keep twice the bytes in flight per CU and halve the number of round trips per block, WITHOUT doubling the
+// split-K slabs the way a second block per CU would (one slab per block, 8 waves reduced in fixed order).
+template <typename T, int KS, int NVH, bool GQ, int TPX, int OCC, int NG = 1>
+__global__ __launch_bounds__(256 * NG, OCC) void wgrad_kernel(const WgK k) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KV = ET<T>::KV, TAPS = KS * KS;
     constexpr int KSTEP = 4 * KV;               // pixels per MFMA K step (32 bf16 / 16 f32)
@@ -70,13 +77,14 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgK k) {
     constexpr int VPX = 32 / KV;                // 16-byte vectors per pixel (32 channels)
     constexpr int NVG = TPX * VPX / 256;        // g staging vectors per thread
     const stl_wgrad& p = k.p;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const int ftid = threadIdx.x, tid = ftid & 255, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const int grp = NG == 1 ? 0 : __builtin_amdgcn_readfirstlane(ftid >> 8);   // wave group (block-local tile stream)
     const int co0 = blockIdx.y * 32, ci0 = blockIdx.z * 32;
     WSTAMP(0);
     float* cgc = reinterpret_cast<float*>(smem + k.off_cg);  // [3][32]
     float* chc = reinterpret_cast<float*>(smem + k.off_ch);  // [2][32]
-    char* sG = smem + k.off_g;
-    char* sH = smem + k.off_h;
+    char* sG = smem + k.off_g + grp * k.grp_stride;
+    char* sH = smem + k.off_h + grp * k.grp_stride;
 
     const int tilepx = p.TH * p.TW;
     const int vpitch = p.Ho + 1;
@@ -205,13 +213,14 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgK k) {
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) acc[a][b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int t = blockIdx.x;
+    int t = blockIdx.x + grp * gridDim.x;    // group g takes tiles blockIdx.x + (NG * i + g) * gridDim.x
     bool have = t < k.npt;
+    bool more = blockIdx.x < k.npt;          // block-uniform loop condition (group 0 has a tile whenever any group has)
     WSTAMP(1);
-    // BatchNorm constants (wave 3: lanes 0-31 those of g, 32-63 those of h): the statistics loads are
+    // BatchNorm constants (wave 3 of group 0: lanes 0-31 those of g, 32-63 those of h): the statistics loads are
     // issued ahead of the first tile's loads, the arithmetic runs while those are in flight
     SrcRaw raw;
-    const bool cw = wave == 3, cg = lane < 32;
+    const bool cw = wave == 3 && grp == 0, cg = lane < 32;
     const int cch = lane & 31;
     const bool cok = cw && (cg ? co0 + cch < p.Co : ci0 + cch < p.Ci);
     if (cok) {
@@ -219,6 +228,12 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgK k) {
         else src_raw_load(p.h, ci0 + cch, p.Ci, raw);
     }
     if (have) setup(t);
+    else {
+#pragma unroll
+        for (int i = 0; i < NVG; ++i) g_go[i] = -1;
+#pragma unroll
+        for (int i = 0; i < NVH; ++i) h_go[i] = -1;
+    }
     issue(have);
     WSTAMP(2);
     if (cw) {
@@ -234,28 +249,37 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgK k) {
     WSTAMP(3);
     bool first = true;
 
-    while (have) {
-        write_lds();
+    int t0 = blockIdx.x;   // group 0's tile of this iteration (loop control)
+    while (more) {
+        write_lds();   // a group without a tile writes zeros (every g_go / h_go is -1)
         __syncthreads();
         if (first) WSTAMP(4);
-        const int tn = t + gridDim.x;
+        const int tn = t + NG * gridDim.x;
         const bool have_n = tn < k.npt;
         if (have_n) setup(tn);
+        else if (NG > 1) {
+#pragma unroll
+            for (int i = 0; i < NVG; ++i) g_go[i] = -1;
+#pragma unroll
+            for (int i = 0; i < NVH; ++i) h_go[i] = -1;
+        }
         issue(have_n);  // next tile's loads fly during the MFMAs
+        if (have) {
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            if (wave + 4 * s < nks) {
-                V16 a[2];
+            for (int s = 0; s < NKS; ++s) {
+                if (wave + 4 * s < nks) {
+                    V16 a[2];
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) a[mt] = frag_tr<T>(sG, rg[s], mt * 16 * (int)sizeof(T), lane);
+                    for (int mt = 0; mt < 2; ++mt) a[mt] = frag_tr<T>(sG, rg[s], mt * 16 * (int)sizeof(T), lane);
 #pragma unroll
-                for (int tap = 0; tap < TAPS; ++tap) {
-                    const int toff = ((tap / KS) * k.HC + (tap % KS)) * k.psh;
+                    for (int tap = 0; tap < TAPS; ++tap) {
+                        const int toff = ((tap / KS) * k.HC + (tap % KS)) * k.psh;
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        const V16 b = frag_tr<T>(sH + toff, rh[s], nt * 16 * (int)sizeof(T), lane);
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const V16 b = frag_tr<T>(sH + toff, rh[s], nt * 16 * (int)sizeof(T), lane);
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) mma16<T>(acc[mt][nt][tap], a[mt], b);
+                            for (int mt = 0; mt < 2; ++mt) mma16<T>(acc[mt][nt][tap], a[mt], b);
+                        }
                     }
                 }
             }
@@ -264,66 +288,115 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgK k) {
         if (first) WSTAMP(5);
         first = false;
         t = tn, have = have_n;
+        t0 += NG * gridDim.x;
+        more = t0 < k.npt;
     }
     WSTAMP(6);
-    // ---- reduce the 4 waves through two LDS regions (fixed order (w0+w2)+(w1+w3): deterministic),
-    // then every wave writes one (mt, nt) quadrant of the block's slab.
-    // region layout: [tile = (mt*2+nt)*TAPS+tap][lane] f32x4 -> conflict-free 16-byte accesses
-    f32x4* red = reinterpret_cast<f32x4*>(smem + k.off_g);
-    constexpr int RT = 4 * TAPS * 64;  // f32x4 per region
-    {
-        f32x4* mine = red + (wave & 1) * RT + lane;
-        if (wave >= 2) {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int tap = 0; tap < TAPS; ++tap) mine[((mt * 2 + nt) * TAPS + tap) * 64] = acc[mt][nt][tap];
-        }
-        __syncthreads();
-        if (wave < 2) {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int tap = 0; tap < TAPS; ++tap) {
-                        f32x4* d = mine + ((mt * 2 + nt) * TAPS + tap) * 64;
-                        *d = acc[mt][nt][tap] + *d;
-                    }
-        }
-        __syncthreads();
-    }
-    WSTAMP(7);
-    {
+    if (NG == 1 && k.quad) {
+        // ---- reduce the 4 waves QUADRANT BY QUADRANT through a small LDS region, fixed order (w0+w2)+(w1+w3):
+        // deterministic.  One quadrant = (mt, nt): TAPS tiles per wave.  The whole-accumulator version needs
+        // 2 x 36.9 KB of LDS (more than the staging tiles), which is what a co-resident conv block cannot use;
+        // per quadrant it is 2 x 9.2 KB for four more barrier pairs.
+        f32x4* red = reinterpret_cast<f32x4*>(smem + k.off_g);
+        constexpr int RQ = TAPS * 64;  // f32x4 per region (one quadrant of one wave)
         float* slab = p.partial + (size_t)blockIdx.x * p.Co * TAPS * p.Ci;
-        const int mt = wave >> 1, nt = wave & 1;
-        const int ci = ci0 + nt * 16 + (lane & 15), co = co0 + mt * 16 + 4 * g;
-        const f32x4* src = red + (wave * TAPS) * 64 + lane;
-        float* dst = slab + (size_t)co * TAPS * p.Ci + ci;
-        const bool ciok = ci < p.Ci;
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const f32x4 v = src[tap * 64] + src[RT + tap * 64];
+        for (int q = 0; q < 4; ++q) {
+            const int mt = q >> 1, nt = q & 1;
+            f32x4* mine = red + (wave & 1) * RQ + lane;
+            if (wave >= 2) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (ciok && co + r < p.Co) dst[((size_t)r * TAPS + tap) * p.Ci] = v[r];
+                for (int tap = 0; tap < TAPS; ++tap) mine[tap * 64] = acc[mt][nt][tap];
+            }
+            __syncthreads();
+            if (wave < 2) {
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap) mine[tap * 64] = acc[mt][nt][tap] + mine[tap * 64];
+            }
+            __syncthreads();
+            {   // all four waves write the quadrant: wave w takes taps w, w + 4, w + 8
+                const int ci = ci0 + nt * 16 + (lane & 15), co = co0 + mt * 16 + 4 * g;
+                float* dst = slab + (size_t)co * TAPS * p.Ci + ci;
+                const bool ciok = ci < p.Ci;
+#pragma unroll
+                for (int tt = 0; tt < (TAPS + 3) / 4; ++tt) {
+                    const int tap = wave + 4 * tt;
+                    if (tap < TAPS) {
+                        const f32x4 v = red[tap * 64 + lane] + red[RQ + tap * 64 + lane];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (ciok && co + r < p.Co) dst[((size_t)r * TAPS + tap) * p.Ci] = v[r];
+                    }
+                }
+            }
+            if (q < 3) __syncthreads();   // the region is rewritten by the next quadrant
+        }
+        WSTAMP(7);
+    } else {
+        // ---- reduce the waves through 2 * NG LDS regions in fixed order ((w0+w2)+(w1+w3) per group, then group 0 +
+        // group 1: deterministic), then every wave writes part of one (mt, nt) quadrant of the block's slab.
+        // region layout: [tile = (mt*2+nt)*TAPS+tap][lane] f32x4 -> conflict-free 16-byte accesses
+        f32x4* red = reinterpret_cast<f32x4*>(smem + k.off_g);
+        constexpr int RT = 4 * TAPS * 64;  // f32x4 per region
+        {
+            f32x4* mine = red + (grp * 2 + (wave & 1)) * RT + lane;
+            if (wave >= 2) {
+    #pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+    #pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+    #pragma unroll
+                        for (int tap = 0; tap < TAPS; ++tap) mine[((mt * 2 + nt) * TAPS + tap) * 64] = acc[mt][nt][tap];
+            }
+            __syncthreads();
+            if (wave < 2) {
+    #pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+    #pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+    #pragma unroll
+                        for (int tap = 0; tap < TAPS; ++tap) {
+                            f32x4* d = mine + ((mt * 2 + nt) * TAPS + tap) * 64;
+                            *d = acc[mt][nt][tap] + *d;
+                        }
+            }
+            __syncthreads();
+        }
+        WSTAMP(7);
+        {
+            float* slab = p.partial + (size_t)blockIdx.x * p.Co * TAPS * p.Ci;
+            const int mt = wave >> 1, nt = wave & 1;
+            const int ci = ci0 + nt * 16 + (lane & 15), co = co0 + mt * 16 + 4 * g;
+            const f32x4* src = red + (wave * TAPS) * 64 + lane;
+            float* dst = slab + (size_t)co * TAPS * p.Ci + ci;
+            const bool ciok = ci < p.Ci;
+            constexpr int TSPLIT = NG == 1 ? TAPS : (TAPS + 1) / 2;   // NG = 2: group 0 writes taps [0, TSPLIT), group 1 the rest
+    #pragma unroll
+            for (int tt = 0; tt < TSPLIT; ++tt) {
+                const int tap = tt + grp * TSPLIT;
+                if (tap < TAPS) {
+                    f32x4 v = src[tap * 64] + src[RT + tap * 64];
+                    if constexpr (NG == 2) v = v + (src[2 * RT + tap * 64] + src[3 * RT + tap * 64]);
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ciok && co + r < p.Co) dst[((size_t)r * TAPS + tap) * p.Ci] = v[r];
+                }
+            }
         }
     }
     WSTAMP(8);
 }
 
-template <typename T, int KS, int NVH, bool GQ, int TPX = 128>
+template <typename T, int KS, int NVH, bool GQ, int TPX = 128, int NG = 1>
 int launch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
     constexpr int OCC = (NVH == 3 && TPX == 128 && sizeof(T) == 2) ? 2 : 1;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, KS, NVH, GQ, TPX, OCC>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, KS, NVH, GQ, TPX, OCC, NG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((wgrad_kernel<T, KS, NVH, GQ, TPX, OCC>), grid, dim3(256), lds, st, k);
+    hipLaunchKernelGGL((wgrad_kernel<T, KS, NVH, GQ, TPX, OCC, NG>), grid, dim3(256 * NG), lds, st, k);
     STL_LAUNCH_CHECK("conv_wgrad");
     return 0;
 }
@@ -609,6 +682,10 @@ int dispatch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
         }
         return stl_set_error("wgrad: 256-pixel tiles need bf16 and a halo of at most 384 pixels (have %d)", k.HP);
     }
+    if constexpr (sizeof(T) == 2) {   // bf16, 128-pixel tiles, small halo: two wave groups per block when the LDS layout was sized for them
+        if (nvh <= 3 && k.grp_stride > 0)
+            return gq ? launch<T, KS, 3, true, 128, 2>(k, grid, lds, st) : launch<T, KS, 3, false, 128, 2>(k, grid, lds, st);
+    }
     if (nvh <= 3) return gq ? launch<T, KS, 3, true>(k, grid, lds, st) : launch<T, KS, 3, false>(k, grid, lds, st);
     if (nvh <= 6) return gq ? launch<T, KS, 6, true>(k, grid, lds, st) : launch<T, KS, 6, false>(k, grid, lds, st);
     if (nvh <= 9) return gq ? launch<T, KS, 9, true>(k, grid, lds, st) : launch<T, KS, 9, false>(k, grid, lds, st);
@@ -672,10 +749,26 @@ extern "C" int stl_conv_wgrad(const stl_wgrad* pp, void* stream) {
     k.off_ch = 3 * 32 * 4;
     k.off_g = 1024;  // consts: g [3][32] floats at 0, h [2][32] floats at 384 -> 640 B used
     int szG = (p.TH * p.TW > 128 ? 256 : 128) * k.psg;
-    const int szRed = 2 * 4 * k.taps * 64 * 16;  // two regions of [4*taps][64] f32x4
+    static const int quad_env = getenv("STL_WGRAD_RED_FULL") ? 0 : 1;
+    k.quad = quad_env;
+    // quadrant-wise reduction: two regions of [taps][64] f32x4; whole accumulators: two (NG = 2: four) of [4*taps][64]
+    int szRed = (k.quad ? 2 : 2 * 4) * k.taps * 64 * 16;
     int szH = k.HP * k.psh;
     k.off_h = k.off_g + szG;
     size_t lds = (size_t)k.off_h + szH;
+    k.grp_stride = 0;
+    {   // two wave groups (NG = 2): bf16, 128-pixel tiles, <= 3 h staging vectors per thread, enough tiles per block
+        // opt-in: isolated 27.1 -> 25.2 us per launch, but a 148 KB / 8-wave block owns its CU and the step gets
+        // SLOWER (19.1 -> 20.4 ms): co-residency with the data-gradient blocks matters more than the launch itself
+        static const int ng_env = getenv("STL_WGRAD_NG") ? atoi(getenv("STL_WGRAD_NG")) : 1;
+        const int nvh = ceil_div(k.HP * (32 / (p.dtype == STL_BF16 ? 8 : 4)), 256);
+        if (ng_env == 2 && p.dtype == STL_BF16 && p.TH * p.TW <= 128 && nvh <= 3 && k.npt >= 2 * p.nsplit) {
+            k.grp_stride = (szG + szH + 15) & ~15;
+            lds = (size_t)k.off_g + 2 * (size_t)k.grp_stride;
+            szRed = 4 * 4 * k.taps * 64 * 16;
+            k.quad = 0;
+        }
+    }
     if ((size_t)k.off_g + szRed > lds) lds = (size_t)k.off_g + szRed;
     STL_CHECK(lds <= 160 * 1024, "wgrad: tile needs %zu B of LDS (>160 KiB)", lds);
     STL_CHECK(p.nsplit <= k.npt || p.nsplit == 1, "wgrad: nsplit %d > tiles %d", p.nsplit, k.npt);
