@@ -255,14 +255,21 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        ts.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        ts.step()
-    barrier()
-    dt = time.perf_counter() - t0
+    import contextlib
+    ctx = contextlib.nullcontext()
+    if os.environ.get("STLPOSE_MAIN_PRIO"):   # experiment: the main (branch-0 / critical chain) stream at another priority
+        hp = torch.cuda.Stream(device=dev, priority=int(os.environ["STLPOSE_MAIN_PRIO"]))
+        hp.wait_stream(torch.cuda.current_stream(dev))
+        ctx = torch.cuda.stream(hp)
+    with ctx:
+        for _ in range(a.warmup):
+            ts.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            ts.step()
+        barrier()
+        dt = time.perf_counter() - t0
     loss = float(ts.loss.item())
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)

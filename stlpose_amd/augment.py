@@ -16,7 +16,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import capi
+from . import capi, ops  # noqa: F401  (ops registers the stlpose:: custom ops)
 
 FLIP_PAIRS = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]   # reference CONSTANTS.py:65
 IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)             # data_loaders.py:59-61
@@ -105,15 +105,13 @@ def crop_batch(images: Sequence[torch.Tensor], centers, scales, rots, flips, ima
         full = np.concatenate([trans[b], [[0.0, 0.0, 1.0]]], 0)
         minv[b] = np.linalg.inv(full)[:2].reshape(-1)
     src = torch.cat(flat).to(dev)
-    out = torch.empty(B, 3, Ho, Wo, dtype=torch.float32, device=dev)
     t_off, t_hw = torch.from_numpy(offs).to(dev), torch.from_numpy(hw).to(dev)
     t_m = torch.from_numpy(minv).to(dev)
     t_f = torch.tensor([int(bool(f)) for f in flips], dtype=torch.int32, device=dev)
-    mean = torch.tensor(IMAGENET_MEAN, device=dev) if normalize else None
-    std = torch.tensor(IMAGENET_STD, device=dev) if normalize else None
-    capi.call("stl_affine_crop", src.data_ptr(), t_off.data_ptr(), t_hw.data_ptr(), t_m.data_ptr(), t_f.data_ptr(), out.data_ptr(),
-              B, Ho, Wo, mean.data_ptr() if normalize else None, std.data_ptr() if normalize else None,
-              torch.cuda.current_stream(dev).cuda_stream)
+    mean = torch.tensor(IMAGENET_MEAN if normalize else (0.0, 0.0, 0.0), device=dev)
+    std = torch.tensor(IMAGENET_STD if normalize else (1.0, 1.0, 1.0), device=dev)
+    with torch.cuda.device(dev):
+        out = torch.ops.stlpose.affine_crop(src, t_off, t_hw, t_m, t_f, Ho, Wo, mean, std)   # custom op -> stl_affine_crop
     return out, trans
 
 

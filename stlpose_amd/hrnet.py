@@ -19,7 +19,7 @@ from typing import Dict, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from . import capi
+from . import capi, ops
 from .arch import ARCHS, Arch, registry
 from .engine import Engine, ParamStore
 
@@ -62,13 +62,12 @@ class _Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, anchor, net, eng):
         ctx.net, ctx.eng = net, eng
-        eng.img.copy_(img)
-        eng.forward(torch.cuda.current_stream().cuda_stream)
+        out = torch.ops.stlpose.hrnet_forward(img, ops.register_engine(eng))   # custom op: the planned forward program
         # The activations backward needs live in the engine's planned buffers, not in ctx: a later
         # forward through the same plan overwrites them.  Remember which forward this node belongs to.
         eng.generation += 1
         ctx.generation = eng.generation
-        return eng.out.clone()
+        return out
 
     @staticmethod
     def backward(ctx, gout):
@@ -80,8 +79,7 @@ class _Fn(torch.autograd.Function):
                 "differentiated, and its activations were overwritten (the reference's autograd keeps one set "
                 "per call; this engine keeps one per plan).  Call backward before the next forward of the same "
                 "shape, or concatenate the inputs into one batch.")
-        eng.dout.copy_(gout)
-        eng.backward(torch.cuda.current_stream().cuda_stream)
+        torch.ops.stlpose.hrnet_backward(gout.contiguous(), ops.register_engine(eng))   # fills the flat gradient buffer
         net._publish_grads()
         return None, None, None, None
 
@@ -213,9 +211,7 @@ class PoseHighResolutionNet(nn.Module):
         if self.training and torch.is_grad_enabled():
             return _Fn.apply(x, self._anchor, self, eng)
         with torch.no_grad():
-            eng.img.copy_(x)
-            eng.forward(torch.cuda.current_stream().cuda_stream)
-            return eng.out.clone()
+            return torch.ops.stlpose.hrnet_forward(x, ops.register_engine(eng))
 
     def load_pretrained(self, pretrained: str = ""):
         """reference HRnet.py:470-499: conv ~ N(0, 0.001), BN gamma 1 / beta 0, then an optional

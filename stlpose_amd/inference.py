@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import torch
 
-from . import capi
+from . import capi, ops  # noqa: F401  (ops registers the stlpose:: custom ops)
 
 FLIP_PAIRS = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]  # CONSTANTS.py:65
 
@@ -24,11 +24,6 @@ def forward_pass(model, img, model_name="HRNet", device=None, flip=False):
         raise NotImplementedError("Wrong model name. Only ['HRNet'] supported")
     output = model(img)
     if flip is True:
-        of = model(img.flip(3)).contiguous()
-        a = output.contiguous()
-        out = torch.empty_like(a)
-        b, j, h, w = a.shape
-        capi.call("stl_flip_merge", a.data_ptr(), of.data_ptr(), out.data_ptr(), _perm(j, a.device).data_ptr(),
-                  b, j, h, w, torch.cuda.current_stream().cuda_stream)
-        output = out
+        of = model(img.flip(3))
+        output = torch.ops.stlpose.flip_merge(output, of, _perm(output.shape[1], output.device))   # custom op -> stl_flip_merge
     return output

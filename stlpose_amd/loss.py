@@ -4,7 +4,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from . import capi
+from . import capi, ops  # noqa: F401  (ops registers the stlpose:: custom ops)
 
 
 class _MSEFn(torch.autograd.Function):
@@ -12,18 +12,8 @@ class _MSEFn(torch.autograd.Function):
     def forward(ctx, output, target, target_weight):
         if not output.is_cuda:
             raise RuntimeError("PersonMSELoss (HIP) needs device tensors; there is no CPU path")
-        o = output.contiguous().float()
-        t = target.to(o.device).contiguous().float()
-        b, j = o.shape[:2]
-        hw = o[0, 0].numel()
-        w = target_weight.to(o.device).float().reshape(b, j).contiguous()
-        dout = torch.empty_like(o)
-        nblk = 256
-        partial = torch.empty(nblk, dtype=torch.float64, device=o.device)
-        loss = torch.empty((), dtype=torch.float32, device=o.device)
-        capi.call("stl_mse_loss", o.data_ptr(), t.data_ptr(), w.data_ptr(), dout.data_ptr(), partial.data_ptr(), nblk,
-                  loss.data_ptr(), b, j, hw, 1.0, torch.cuda.current_stream().cuda_stream)
-        ctx.save_for_backward(dout)
+        loss, dout = torch.ops.stlpose.person_mse(output, target.to(output.device), target_weight.to(output.device), 1.0)
+        ctx.save_for_backward(dout)   # custom op -> stl_mse_loss: loss and d(loss)/d(output) in one pass
         return loss
 
     @staticmethod

@@ -4,7 +4,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from . import capi
+from . import capi, ops  # noqa: F401  (ops registers the stlpose:: custom ops)
 
 
 def _dev(x, device=None) -> torch.Tensor:
@@ -19,13 +19,7 @@ def _dev(x, device=None) -> torch.Tensor:
 
 def max_preds_device(hm: torch.Tensor):
     """-> (idx int32 (B,J), maxvals f32 (B,J,1), preds f32 (B,J,2)) as device tensors."""
-    b, j, h, w = hm.shape
-    idx = torch.empty(b, j, dtype=torch.int32, device=hm.device)
-    mx = torch.empty(b, j, 1, dtype=torch.float32, device=hm.device)
-    preds = torch.empty(b, j, 2, dtype=torch.float32, device=hm.device)
-    capi.call("stl_heatmap_argmax", hm.data_ptr(), idx.data_ptr(), mx.data_ptr(), preds.data_ptr(), b * j, h, w,
-              torch.cuda.current_stream().cuda_stream)
-    return idx, mx, preds
+    return torch.ops.stlpose.heatmap_argmax(hm)   # custom op -> stl_heatmap_argmax (ops.py)
 
 
 def get_max_preds_hrnet(scaled_heats, thr=0.1):
@@ -44,10 +38,7 @@ def get_final_preds_hrnet(heatmaps, center, scale):
     b, j, h, w = hm.shape
     c = _dev(np.asarray(center, dtype=np.float32), hm.device)
     s = _dev(np.asarray(scale, dtype=np.float32), hm.device)
-    preds = torch.empty(b, j, 2, dtype=torch.float32, device=hm.device)
-    mx = torch.empty(b, j, 1, dtype=torch.float32, device=hm.device)
-    capi.call("stl_final_preds", hm.data_ptr(), c.data_ptr(), s.data_ptr(), preds.data_ptr(), mx.data_ptr(), b, j, h, w,
-              torch.cuda.current_stream().cuda_stream)
+    preds, mx = torch.ops.stlpose.final_preds(hm, c, s)   # custom op -> stl_final_preds
     p = preds.cpu().numpy()
     # coords in heatmap space = forward crop transform of preds (kept for API parity)
     sc = (w / (np.asarray(scale, dtype=np.float64)[:, 0] * 200.0))[:, None]

@@ -8,7 +8,7 @@ from typing import Sequence, Tuple
 
 import torch
 
-from . import capi
+from . import capi, ops  # noqa: F401  (ops registers the stlpose:: custom ops)
 
 
 def generate_targets(joints: torch.Tensor, joints_vis: torch.Tensor, heatmap_size: Sequence[int], image_size: Sequence[int],
@@ -24,8 +24,6 @@ def generate_targets(joints: torch.Tensor, joints_vis: torch.Tensor, heatmap_siz
     v = (v[..., 0] if v.dim() == 3 else v).contiguous()
     b, nj = j.shape[:2]
     wh, hh = int(heatmap_size[0]), int(heatmap_size[1])
-    target = torch.empty(b, nj, hh, wh, dtype=torch.float32, device=dev)
-    tw = torch.empty(b, nj, dtype=torch.float32, device=dev)
-    capi.call("stl_gaussian_targets", j.data_ptr(), v.data_ptr(), target.data_ptr(), tw.data_ptr(), b, nj, hh, wh,
-              float(image_size[0]) / wh, float(image_size[1]) / hh, float(sigma), torch.cuda.current_stream(dev).cuda_stream)
+    with torch.cuda.device(dev):
+        target, tw = torch.ops.stlpose.gaussian_targets(j, v, hh, wh, float(image_size[0]) / wh, float(image_size[1]) / hh, float(sigma))
     return target, tw.view(b, nj, 1)

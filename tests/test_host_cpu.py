@@ -98,3 +98,24 @@ def test_choose_tile_bounds():
     for (B, H, W, s, ks) in [(32, 96, 72, 1, 3), (32, 12, 9, 1, 3), (2, 8, 6, 1, 1), (32, 48, 36, 2, 3), (1, 3, 2, 1, 3)]:
         th, tw = choose_tile(B, H, W, s, ks, 2)
         assert 1 <= th and 1 <= tw <= W and th * tw <= 128
+
+
+def test_torch_library_ops_are_registered_and_gpu_only():
+    """north_star: 'hand-written HIP kernels through PyTorch-ROCm custom ops'.  Every op of the ``stlpose``
+    namespace exists, has only a CUDA (HIP) kernel -- a CPU tensor is refused by the dispatcher, there is no CPU
+    fallback -- and is traceable through its fake implementation."""
+    import torch
+    from stlpose_amd import ops
+    for name in ops.OPS:
+        assert hasattr(torch.ops.stlpose, name), name
+    with pytest.raises(NotImplementedError, match="CPU"):
+        torch.ops.stlpose.heatmap_argmax(torch.zeros(1, 17, 4, 4))
+    with pytest.raises(NotImplementedError, match="CPU"):
+        torch.ops.stlpose.person_mse(torch.zeros(1, 17, 4, 4), torch.zeros(1, 17, 4, 4), torch.ones(1, 17, 1), 1.0)
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        hm = torch.empty(2, 17, 8, 6, device="cuda")
+        idx, mx, preds = torch.ops.stlpose.heatmap_argmax(hm)
+        assert idx.shape == (2, 17) and mx.shape == (2, 17, 1) and preds.shape == (2, 17, 2)
+        loss, dout = torch.ops.stlpose.person_mse(hm, hm, torch.empty(2, 17, 1, device="cuda"), 1.0)
+        assert loss.shape == () and dout.shape == hm.shape
