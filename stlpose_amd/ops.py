@@ -34,7 +34,7 @@ def _define(schema: str, fn, fake=None):
 
 
 # ------------------------------------------------------------------ loss (reference lib/loss.py:71-94)
-def _mse(output: torch.Tensor, target: torch.Tensor, weight: torch.Tensor, scale: float) -> Tuple[torch.Tensor, torch.Tensor]:
+def _mse(output: torch.Tensor, target: torch.Tensor, weight: torch.Tensor, scale: float = 1.0) -> Tuple[torch.Tensor, torch.Tensor]:
     o, t = output.contiguous().float(), target.contiguous().float()
     b, j = o.shape[:2]
     w = weight.float().reshape(b, j).contiguous()

@@ -233,7 +233,9 @@ def test_three_train_steps_vs_oracle_and_torch_optim(opt):
         if k.endswith("num_batches_tracked"):
             assert int(got) == int(v) == 3
         elif "running_" in k:
-            np.testing.assert_allclose(got.numpy(), v.numpy(), rtol=2e-3, atol=2e-4, err_msg=k)
+            # a ReLU that sits on opposite sides of zero in the two fp32 implementations changes single gradient
+            # elements by ~1e-3 (profiles/r02_fp32_layerwise_vs_fp64.txt: torch fp32 does the same against fp64)
+            np.testing.assert_allclose(got.numpy(), v.numpy(), rtol=2e-3, atol=1e-3, err_msg=k)
         else:
             du_ref, du_hip = (v - w0[k]).double(), (got - w0[k]).double()
             num += float((du_hip - du_ref).pow(2).sum())

@@ -1,0 +1,30 @@
+"""Diagnostic: per-parameter gradient error of the fp32 HIP path vs an fp64 oracle, in backward order (tiny net)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import hrnet_ref, pose_ref
+from tests.golden.make_golden import synth_batch
+from stlpose_amd import PersonMSELoss, PoseHighResolutionNet
+arch = sys.argv[1] if len(sys.argv) > 1 else "tiny"
+B, H, W = (2, 96, 64) if arch == "tiny" else (2, 256, 192)
+img, tgt, tw = synth_batch(B, H, W, seed=11)
+res = {}
+for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+    ref = hrnet_ref.load_synth(hrnet_ref.RefPoseNet(arch)).to(dt).train()
+    out = ref(torch.from_numpy(img).to(dt)); out.retain_grad()
+    loss = pose_ref.person_mse_loss(out, torch.from_numpy(tgt).to(dt), torch.from_numpy(tw).to(dt))
+    loss.backward()
+    res[name] = dict(out=out.detach().double(), dout=out.grad.double(), g={k: p.grad.double() for k, p in ref.named_parameters()})
+m = PoseHighResolutionNet(arch, "fp32")
+m.load_state_dict({k: torch.from_numpy(hrnet_ref.synth_tensor(k, tuple(v.shape))) for k, v in m.state_dict().items()})
+m = m.cuda().train()
+out = m(torch.from_numpy(img).cuda()); out.retain_grad()
+loss = PersonMSELoss()(out, torch.from_numpy(tgt).cuda(), torch.from_numpy(tw).cuda()); loss.backward()
+rel = lambda a, b: float((a.double().cpu() - b).abs().max() / (b.abs().max() + 1e-30))
+print("out: hip", rel(out.detach(), res["f64"]["out"]), "torch32", rel(res["f32"]["out"], res["f64"]["out"]))
+print("dout: hip", rel(out.grad, res["f64"]["dout"]), "torch32", rel(res["f32"]["dout"], res["f64"]["dout"]))
+names = [k for k, _ in m.named_parameters()]
+for k in reversed(names):
+    e = rel(dict(m.named_parameters())[k].grad, res["f64"]["g"][k]); e32 = rel(res["f32"]["g"][k], res["f64"]["g"][k])
+    if k.endswith("conv1.weight") or k.endswith("conv2.weight") or "fuse" in k and k.endswith("0.weight") or k.startswith(("final", "conv", "transition")):
+        print(f"{k:50s} hip {e:.1e} torch32 {e32:.1e}")
