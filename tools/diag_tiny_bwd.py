@@ -7,7 +7,7 @@ from tests.golden.make_golden import synth_batch
 from stlpose_amd import PersonMSELoss, PoseHighResolutionNet
 arch = sys.argv[1] if len(sys.argv) > 1 else "tiny"
 B, H, W = (2, 96, 64) if arch == "tiny" else (2, 256, 192)
-img, tgt, tw = synth_batch(B, H, W, seed=11)
+img, tgt, tw = synth_batch(B, H, W, seed=int(sys.argv[2]) if len(sys.argv) > 2 else 11)
 res = {}
 for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
     ref = hrnet_ref.load_synth(hrnet_ref.RefPoseNet(arch)).to(dt).train()
