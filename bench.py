@@ -192,10 +192,45 @@ def extra_vgg_cfg4(dev, reps=5):
                                   sample="oracle.vgg_ref fp32, 2 pairs of 3x512x512, resize=False, one evaluation"))
 
 
+def extra_vgg19_style(dev, reps=3):
+    """BASELINE configs[3] by name: VGG19 content + Gram style loss forward, 512 x 512, batch 16 (stylised, content and
+    style batches = 48 images through conv1_1 .. conv5_1 + 160 Gram launches).  V2 has no reference item: parity
+    unpinned (oracle = published-method restatement)."""
+    from oracle import vgg_ref
+    from stlpose_amd.vgg19_style import VGG19StyleLoss, vgg19_flops_per_image
+    w = vgg_ref.synth_vgg19_weights()
+    g = torch.Generator().manual_seed(19)
+    x, c, s_ = (torch.rand(16, 3, 512, 512, generator=g) for _ in range(3))
+    fl = 48 * vgg19_flops_per_image(512, 512)
+    res = {}
+    for dt_name, peak in (("fp32", 157.3), ("bf16", MFMA_PEAK_BF16)):
+        m = VGG19StyleLoss(state_dict=w, compute_dtype=dt_name).to(dev)
+        xd, cd, sd = x.to(dev), c.to(dev), s_.to(dev)
+        m(xd, cd, sd)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            tot, cl, sl = m(xd, cd, sd)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        tf = fl / dt / 1e12
+        res[dt_name] = dict(ms_per_loss=round(dt * 1e3, 3), triplets_per_sec=round(16 / dt, 2), content=float(cl.item()), style=float(sl.item()),
+                            roofline=dict(bound="mfma", achieved=round(tf, 2), peak=peak, unit="TFLOP/s", frac=round(tf / peak, 4), traffic=None))
+        del m
+        torch.cuda.empty_cache()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    t0 = time.time()
+    with torch.no_grad():
+        vgg_ref.vgg19_style_content_loss(x[:1], c[:1], s_[:1], w)
+    return dict(metric="image triplets/sec VGG19 content + Gram style loss forward 512x512 bs=16 (cfg4; V2, parity unpinned)", unit="triplets/sec", **res,
+                cpu_baseline=dict(value=round(1 / (time.time() - t0), 3), unit="triplets/sec", cores=torch.get_num_threads(), kind="port",
+                                  sample="oracle.vgg_ref.vgg19_style_content_loss fp32, 1 triplet of 3x512x512, one evaluation"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--arch", default="w32")
     ap.add_argument("--height", type=int, default=384)
@@ -316,7 +351,7 @@ def main():
             torch.cuda.empty_cache()
             extras = {}
             for name, fn in (("fp32_path", lambda: extra_fp32_path(a.arch, a.batch, a.height, a.width, dev)),
-                             ("vgg_cfg4", lambda: extra_vgg_cfg4(dev))):
+                             ("vgg_cfg4", lambda: extra_vgg_cfg4(dev)), ("vgg19_style_cfg4", lambda: extra_vgg19_style(dev))):
                 try:
                     extras[name] = fn()
                 except Exception as e:   # an extra leg must never take the headline line down

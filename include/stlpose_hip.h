@@ -254,6 +254,8 @@ int stl_affine_crop(const uint8_t* src, const int64_t* src_off, const int32_t* s
 int stl_maxpool2x2(int dtype, const void* x, void* out, int B, int H, int W, int C, void* stream);
 int stl_l1_partial(int dtype, const void* a, const void* b, int64_t n, double* partial, int nblk,
                    void* stream); /* partial[i] = sum |a-b| over block i's share */
+/* Same with squared differences (content / Gram MSE of the VGG19 style loss, V2 -- no reference counterpart). */
+int stl_l2_partial(int dtype, const void* a, const void* b, int64_t n, double* partial, int nblk, void* stream);
 int stl_bilinear_nchw(const float* in, float* out, int B, int C, int H, int W, int Ho, int Wo,
                       void* stream); /* F.interpolate(mode='bilinear', align_corners=False) */
 int stl_sum_partials(const double* partial, int n, double scale, float* out, int accumulate, void* stream);

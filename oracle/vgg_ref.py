@@ -78,3 +78,53 @@ def vgg_perceptual_loss(inp: torch.Tensor, tgt: torch.Tensor, weights, resize: b
     for fx, fy in zip(vgg_features(inp, weights), vgg_features(tgt, weights)):
         loss = loss + F.l1_loss(fx, fy)
     return loss
+
+
+# ------------------------------------------------------------------------------------------------ V2 (no reference item)
+# VGG19 content + Gram style loss named by BASELINE.json configs[3]/[4].  /root/reference contains nothing of the kind
+# (grep gram|vgg19|adain -> 0 hits): PARITY UNPINNED by construction.  Restated from the published
+# method (Gatys et al. 2016 / Johnson et al. 2016): torchvision VGG19 configuration "E" (conv counts 2,2,4,4,4), style
+# taps relu1_1, relu2_1, relu3_1, relu4_1, relu5_1, content tap relu4_2, Gram G = F F^T / (C*H*W),
+# loss = content_weight * mse(F_x, F_c) + style_weight * sum_l mse(G_l(x), G_l(s)).
+VGG19_CONVS = [(0, 3, 64, False), (2, 64, 64, False), (5, 64, 128, True), (7, 128, 128, False), (10, 128, 256, True),
+               (12, 256, 256, False), (14, 256, 256, False), (16, 256, 256, False), (19, 256, 512, True), (21, 512, 512, False),
+               (23, 512, 512, False), (25, 512, 512, False), (28, 512, 512, True)]   # (features idx, cin, cout, pool before)
+VGG19_STYLE_TAPS = (0, 2, 4, 8, 12)   # positions in VGG19_CONVS: relu1_1, 2_1, 3_1, 4_1, 5_1
+VGG19_CONTENT_TAP = 9                 # relu4_2
+
+
+def synth_vgg19_weights(seed: int = 0) -> Dict[str, torch.Tensor]:
+    out = {}
+    for idx, cin, cout, _ in VGG19_CONVS:
+        for leaf, shape in (("weight", (cout, cin, 3, 3)), ("bias", (cout,))):
+            key = f"features.{idx}.{leaf}"
+            rng = np.random.Generator(np.random.PCG64((zlib.crc32(("vgg19." + key).encode()) + 7919 * seed) & 0xFFFFFFFF))
+            v = rng.normal(0.0, np.sqrt(2.0 / (cin * 9)), shape) if leaf == "weight" else rng.normal(0.0, 0.05, shape)
+            out[key] = torch.from_numpy(v.astype(np.float32))
+    return out
+
+
+def vgg19_taps(x: torch.Tensor, weights: Dict[str, torch.Tensor]):
+    """ImageNet-normalised NCHW batch -> list of the 13 post-ReLU feature maps."""
+    feats = []
+    for idx, _, _, pool in VGG19_CONVS:
+        if pool:
+            x = F.max_pool2d(x, 2, 2)
+        x = F.relu(F.conv2d(x, weights[f"features.{idx}.weight"], weights[f"features.{idx}.bias"], padding=1))
+        feats.append(x)
+    return feats
+
+
+def gram(f: torch.Tensor) -> torch.Tensor:
+    b, c, h, w = f.shape
+    m = f.reshape(b, c, h * w)
+    return torch.bmm(m, m.transpose(1, 2)) / (c * h * w)
+
+
+def vgg19_style_content_loss(x, content, style, weights, content_weight=1.0, style_weight=1e5):
+    mean = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+    fx, fc, fs = (vgg19_taps((t - mean) / std, weights) for t in (x, content, style))
+    c_loss = F.mse_loss(fx[VGG19_CONTENT_TAP], fc[VGG19_CONTENT_TAP])
+    s_loss = sum(F.mse_loss(gram(fx[i]), gram(fs[i])) for i in VGG19_STYLE_TAPS)
+    return content_weight * c_loss + style_weight * s_loss, c_loss, s_loss

@@ -134,6 +134,7 @@ SIGNATURES = {
     "stl_affine_crop": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp],
     "stl_maxpool2x2": [i32, vp, vp, i32, i32, i32, i32, vp],
     "stl_l1_partial": [i32, vp, vp, i64, vp, i32, vp],
+    "stl_l2_partial": [i32, vp, vp, i64, vp, i32, vp],
     "stl_bilinear_nchw": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "stl_sum_partials": [vp, i32, C.c_double, vp, i32, vp],
     "stl_nchw_to_nhwc": [i32, vp, vp, i32, i32, i32, i32, vp],

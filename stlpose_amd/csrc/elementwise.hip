@@ -725,7 +725,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const void* x, void* out, 
     }
 }
 
-template <typename T>
+template <typename T, bool SQ>
 __global__ __launch_bounds__(256) void l1_kernel(const void* a, const void* b, size_t nvec, double* partial) {
     double acc = 0.0;
     for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (size_t)gridDim.x * 256) {
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(256) void l1_kernel(const void* a, const void* b, s
         load8<T>(b, v * 8, y);
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += fabsf(x[j] - y[j]);
+        for (int j = 0; j < 8; ++j) s += SQ ? (x[j] - y[j]) * (x[j] - y[j]) : fabsf(x[j] - y[j]);
         acc += (double)s;
     }
     __shared__ double sred[4];
@@ -1173,10 +1173,20 @@ extern "C" int stl_maxpool2x2(int dtype, const void* x, void* out, int B, int H,
 extern "C" int stl_l1_partial(int dtype, const void* a, const void* b, int64_t n, double* partial, int nblk, void* stream) {
     STL_CHECK(n % 8 == 0 && nblk >= 1, "l1: n%%8");
     if (dtype == STL_BF16)
-        hipLaunchKernelGGL(l1_kernel<__bf16>, dim3(nblk), dim3(256), 0, ST, a, b, (size_t)n / 8, partial);
+        hipLaunchKernelGGL((l1_kernel<__bf16, false>), dim3(nblk), dim3(256), 0, ST, a, b, (size_t)n / 8, partial);
     else
-        hipLaunchKernelGGL(l1_kernel<float>, dim3(nblk), dim3(256), 0, ST, a, b, (size_t)n / 8, partial);
+        hipLaunchKernelGGL((l1_kernel<float, false>), dim3(nblk), dim3(256), 0, ST, a, b, (size_t)n / 8, partial);
     STL_LAUNCH_CHECK("l1_partial");
+    return 0;
+}
+
+extern "C" int stl_l2_partial(int dtype, const void* a, const void* b, int64_t n, double* partial, int nblk, void* stream) {
+    STL_CHECK(n % 8 == 0 && nblk >= 1, "l2: n%%8");
+    if (dtype == STL_BF16)
+        hipLaunchKernelGGL((l1_kernel<__bf16, true>), dim3(nblk), dim3(256), 0, ST, a, b, (size_t)n / 8, partial);
+    else
+        hipLaunchKernelGGL((l1_kernel<float, true>), dim3(nblk), dim3(256), 0, ST, a, b, (size_t)n / 8, partial);
+    STL_LAUNCH_CHECK("l2_partial");
     return 0;
 }
 
