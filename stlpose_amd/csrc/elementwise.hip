@@ -581,8 +581,18 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* partials
         if (i >= tot) return;
         const int co = (int)(i / (e.Ci * t)), rem = (int)(i - (int64_t)co * e.Ci * t), ci = rem / t, tap = rem - ci * t;
         const int64_t src = e.patch ? ((int64_t)co * cik + tap * e.Ci + ci) : (((int64_t)co * t + tap) * cik + ci);
+        // eight slabs in flight (a serial loop is one memory round trip per slab: 124 us for the 128 slabs of the
+        // stem's patch conv, at the very end of the step); fixed summation order -> deterministic
+        const float* pp = partials + e.part_off + src;
         float s = 0.f;
-        for (int k = 0; k < e.nsplit; ++k) s += partials[e.part_off + k * slab + src];
+        int k = 0;
+        for (; k + 8 <= e.nsplit; k += 8) {
+            float a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = pp[(int64_t)(k + u) * slab];
+            s += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        }
+        for (; k < e.nsplit; ++k) s += pp[(int64_t)k * slab];
         grads[e.grad_off + i] = s;
     }
 }
