@@ -162,9 +162,12 @@ class Engine:
         self.nstreams = int(os.environ.get("STLPOSE_STREAMS", "4"))
         # weight-gradient streams: "0" = none (same stream as the branch), "1" = one per branch stream,
         # "n<k>" = k shared streams (branch s -> weight-gradient stream s % k)
-        wgs = os.environ.get("STLPOSE_WGRAD_STREAMS", "1")
-        self.wgrad_streams = wgs != "0"
-        self.nwstreams = 0 if wgs == "0" else (int(wgs[1:]) if wgs.startswith("n") else self.nstreams)
+        # "auto": no extra streams -- every off-chain launch (weight gradients, slab reductions) is list-scheduled
+        # onto the branch stream that is free first (_balance_streams)
+        wgs = os.environ.get("STLPOSE_WGRAD_STREAMS", "auto")
+        self.wgrad_auto = wgs == "auto"
+        self.wgrad_streams = wgs not in ("0", "auto")
+        self.nwstreams = 0 if not self.wgrad_streams else (int(wgs[1:]) if wgs.startswith("n") else self.nstreams)
         self._stream = 0
         self._side = None
         self._stats_used = 0
@@ -369,8 +372,23 @@ class Engine:
             b["op"] = len(ops) - 1
             self.buckets.append(b)
             bk.update(done=0, hi=bk["lo"], slab0=len(self.slabs), reads=[])
+        self._nactive: Dict[int, int] = {}   # id(desc) -> branch streams busy with the data-gradient chain around that op
+        cur_active = self.nstreams
+
+        def active_of(key: str) -> int:
+            if key.startswith("stage"):
+                return int(key[5])
+            if key.startswith("transition") and key[10] in "23":
+                return int(key[10])
+            return 1 if not key.startswith("final") else self.nstreams
+        n_before = 0
         for node in reversed(self.tape):
             kind = node[0]
+            for o in ops[n_before:]:
+                self._nactive.setdefault(id(o[1]), cur_active)
+            n_before = len(ops)
+            if kind == "conv":
+                cur_active = min(self.nstreams, active_of(node[3].key))
             bucket_close()   # after the previous node's ops: closes a bucket when a complete suffix is large enough
             if kind == "head":
                 _, x, key, joints = node
@@ -513,6 +531,8 @@ class Engine:
                 d.out = out.data_ptr()
                 ops.append(("stl_conv_forward", d, strm, dreads, [out.data_ptr()] + dwrites))
         bucket_close(force=True)
+        for o in ops[n_before:]:
+            self._nactive.setdefault(id(o[1]), cur_active)
         assert bk["done"] == 0 and bk["hi"] == 0, "gradient buckets do not cover the parameter buffer"
         # slab arena + reduce table
         self.slab_arena = torch.empty(max(self._slab_elems, 1), dtype=torch.float32, device=self.dev)
@@ -543,9 +563,59 @@ class Engine:
             i0, i1 = bisect.bisect_left(bn_off, b["lo"]), bisect.bisect_left(bn_off, b["hi"])
             br.rstats, br.grads = self.rstats.data_ptr(), st.grads.data_ptr()
             br.tab, br.n = self._bn_tab.data_ptr() + i0 * C.sizeof(capi.BNRec), i1 - i0
-        self.bwd_ops = self._lag_wgrads(ops, int(os.environ.get("STLPOSE_WGRAD_LAG", "0")))
+        ops = self._lag_wgrads(ops, int(os.environ.get("STLPOSE_WGRAD_LAG", "0")))
+        self.bwd_ops = self._balance_streams(ops) if self.wgrad_auto else ops
         for b in self.buckets:   # bucket events are addressed by op index
             b["op"] = next(i for i, o in enumerate(self.bwd_ops) if o[1] is b["br"])
+
+    def _op_cost_us(self, op) -> float:
+        """Rough duration of a backward launch for the list scheduler: a fixed launch + latency-chain part plus its
+        bytes at ~2 TB/s (what these launches achieve)."""
+        name, d = op[0], op[1]
+        esz = self.esz
+        if name == "stl_conv_forward":
+            src = d.B * d.Hi * d.Wi * d.Ci * (2 if d.src.mode == capi.SRC_BNBWD else 1)
+            out = d.B * d.Ho * d.Wo * d.Co * (1 + bool(d.mask_y) + bool(d.addend) + bool(d.mask_z))
+            extra = d.B * d.Ho * d.Wo * d.Co if d.partial else 0
+            return 12.0 + (src + out + extra) * esz / 2.0e6 + (10.0 if d.partial else 0.0)
+        if name == "stl_conv_wgrad":
+            by = (d.B * d.Hi * d.Wi * d.Ci + d.B * d.Ho * d.Wo * d.Co * (2 if d.g.mode == capi.SRC_BNBWD else 1)) * esz
+            return 16.0 + (by + 2.0 * d.nsplit * d.Co * d.Ci * d.ks * d.ks * 4) / 2.0e6
+        if name == "stl_fuse_backward":
+            return 8.0 + d.B * d.H * d.W * d.C * (d.ngrads + 2 + d.nbn) * esz / 3.0e6
+        if name == "stl_upsample_backward":
+            return 8.0 + d.B * d.H * d.W * d.C * ((1 << (2 * d.shift)) + 2) * esz / 3.0e6
+        if name == "stl_head_backward":
+            return 80.0
+        if name == "stl_reduce_slabs_range":
+            return 20.0 + 80.0 * d.nblocks / 1100.0
+        return 5.0
+
+    def _balance_streams(self, ops):
+        """Static placement of the off-chain backward launches (weight gradients, slab reductions, BatchNorm
+        gradients) onto the branch streams -- one hardware queue each.  (With extra weight-gradient streams two
+        streams share a queue and every switch between them costs ~6 us: 475 such gaps per step in
+        profiles/r02_trace_default_summary.txt; on its own branch stream a weight gradient delays the
+        data-gradient chain.)  Where the network has fewer branches than streams -- stage 3, stage 2, and the
+        single-branch tail (layer1, stem), 40 % of backward -- the idle queues take the off-chain work: each such
+        launch goes to the least-loaded stream among the idle ones and its own, by accumulated estimated time."""
+        acc = [0.0] * self.nstreams
+        out = []
+        for op in ops:
+            name, desc, strm, reads, writes = op
+            cost = self._op_cost_us(op)
+            if name in ("stl_conv_wgrad", "stl_reduce_slabs_range", "stl_bn_grads_range"):
+                active = self._nactive.get(id(desc), self.nstreams)
+                own = strm % self.nstreams
+                if os.environ.get("STLPOSE_BALANCE", "idle") == "idle":
+                    cands = list(range(active, self.nstreams)) + [own]
+                else:   # any stream: a foreign weight gradient is issued behind that branch's ops of the module and
+                    cands = range(self.nstreams)   # only waits for a data gradient the next exchange needs anyway
+                strm = min(cands, key=lambda s_: (acc[s_], s_ != own))
+            acc[strm] += cost
+            out.append((name, desc, strm, reads, writes))
+        self.sched_estimate_us = list(acc)
+        return out
 
     @staticmethod
     def _lag_wgrads(ops, lag: int):

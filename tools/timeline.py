@@ -47,6 +47,22 @@ for r in win:
     k = short(r['Kernel_Name']); agg[k][0] += 1; agg[k][1] += (r['e'] - r['s']) / 1e3
 for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
     print(f"{k:44s} n {c:4d}  avg {t / c:8.1f} us  {t / 1e3:7.2f} ms")
+# gaps between consecutive kernels of one hardware queue: a host that cannot keep up with the eager replay would
+# show as a floor of >= 3-4 us under EVERY launch; dependency waits (branch imbalance, exchange joins) show as a
+# few long gaps instead
+buckets = [(0, 0.5), (0.5, 2), (2, 5), (5, 10), (10, 50), (50, 1e9)]
+gh = collections.Counter(); gt = collections.Counter()
+for qid in sorted(q):
+    ks = sorted((r for r in win if r['Queue_Id'] == qid), key=lambda r: r['s'])
+    last_e = None
+    for r in ks:
+        if last_e is not None:
+            g = max(0.0, (r['s'] - last_e) / 1e3)
+            for lo, hi in buckets:
+                if lo <= g < hi:
+                    gh[(lo, hi)] += 1; gt[(lo, hi)] += g
+        last_e = r['e'] if last_e is None else max(last_e, r['e'])
+print("same-queue gaps (us): " + ", ".join(f"[{lo},{hi if hi < 1e8 else 'inf'}) n={gh[(lo, hi)]} sum={gt[(lo, hi)] / 1e3:.2f}ms" for lo, hi in buckets))
 # phases: forward ends at mse kernel
 mse = [r for r in win if 'mse_kernel' in r['Kernel_Name']]
 if mse:
