@@ -84,14 +84,33 @@ def _exchange_module(g, p: str, xs: List, widths: Sequence[int], nblocks: int, f
             x = g.fuse([(h, 0), (x, 0)], relu=True)
         xs[b] = x
     outs = []
+    # Exchange: out_i = ReLU(sum_j f_ij(x_j)).  The f_ij chains of one module are independent of each other, so they
+    # are spread over the branch streams by estimated cost (emission order -- and with it the state_dict order --
+    # is untouched): on "stream i for everything that feeds out_i" the deepest output serialises up to six
+    # stride-2 convolutions (0->3: 3 hops, 1->3: 2, 2->3: 1) while the other queues idle.
+    ns = max(n, getattr(g, "nstreams", n))   # streams without a branch in this stage are idle: use them too
+    load = [0.0] * ns
+    balance = getattr(g, "balance_exchange", False)
     for i in range(n if full else 1):
-        g.set_stream(i)
         terms = []
         for j in range(n):
             q = f"{p}.fuse_layers.{i}.{j}"
             if j == i:
                 terms.append((xs[j], 0))
-            elif j > i:  # 1x1 conv + BN, nearest-upsampled 2^(j-i) inside the sum kernel
+                continue
+            strm = i
+            if balance:
+                cost, t, c_in = 0.0, xs[j], None
+                if j > i:
+                    cost = g.est_cost(xs[j], widths[i], 1, 1)
+                else:
+                    for k in range(i - j):
+                        last = k == i - j - 1
+                        cost += g.est_cost(xs[j], widths[i] if last else widths[j], 3, 2, hop=k)
+                strm = min(range(ns), key=lambda s_: (load[s_], s_ != i))
+                load[strm] += cost
+            g.set_stream(strm)
+            if j > i:  # 1x1 conv + BN, nearest-upsampled 2^(j-i) inside the sum kernel
                 terms.append((g.conv_bn(f"{q}.0", f"{q}.1", xs[j], widths[i], 1, 1, False), j - i))
             else:        # (i-j) stride-2 3x3 hops, ReLU after all but the last
                 t = xs[j]
@@ -99,6 +118,7 @@ def _exchange_module(g, p: str, xs: List, widths: Sequence[int], nblocks: int, f
                     last = k == i - j - 1
                     t = g.conv_bn(f"{q}.{k}.0", f"{q}.{k}.1", t, widths[i] if last else widths[j], 3, 2, not last)
                 terms.append((t, 0))
+        g.set_stream(i)
         outs.append(g.fuse(terms, relu=True))
     g.set_stream(0)
     return outs

@@ -225,6 +225,17 @@ class Engine:
     def set_stream(self, s: int):
         self._stream = s % self.nstreams
 
+    # opt-in: measured 18.4 -> 18.8 ms/step -- every chain moved to another stream pays a cross-stream event wait
+    # (~6 us) at both ends, more than the serialisation it removes
+    balance_exchange = os.environ.get("STLPOSE_BALANCE_EXCHANGE", "0") != "0"
+
+    def est_cost(self, x: "Act", cout: int, ks: int, stride: int, hop: int = 0) -> float:
+        """Estimated duration (us) of one conv of an exchange chain (arch._exchange_module): launch + latency chain
+        plus input and output bytes at ~2 TB/s; hop k of a stride-2 chain sees a map 4^k times smaller."""
+        h, w = x.H >> hop, x.W >> hop
+        ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
+        return 12.0 + (x.B * h * w * x.C + x.B * ho * wo * cout) * self.esz / 2.0e6
+
     def stem_input(self) -> Act:
         B, H, W = self.B, self.H, self.W
         Ho, Wo = H // 2, W // 2
