@@ -144,3 +144,34 @@ def test_fused_backward_matches_separate_launches_at_full_size(monkeypatch, dt):
         d = float((x - y).abs().max()) / (float(x.abs().max()) + 1e-20)
         c = float(torch.dot(x, y) / (x.norm() * y.norm() + 1e-30))
         assert d < tol and c > cosmin, (k, d, c)
+
+
+def test_backward_stream_layouts_give_the_same_gradients(monkeypatch):
+    """The backward planner's stream layouts (off-chain launches list-scheduled onto idle branch streams = default,
+    inline on the branch stream, extra weight-gradient streams, launch lag) only move launches between queues:
+    losses identical, gradients identical up to the order of the fp64 statistics atomics."""
+    img, tgt, tw = _batch(4, 256, 192, seed=13)
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        torch.manual_seed(17)
+        m = PoseHighResolutionNet("w32", "fp32").cuda()
+        ts = TrainStep(m, 4, 256, 192, optimizer="sgd", lr=0.0, momentum=0.0)
+        ts.load_batch(img.cuda(), tgt.cuda(), tw.cuda())
+        l = float(ts.step().item())
+        torch.cuda.synchronize()
+        g = ts.store.grads.clone()
+        n = ts.eng.total_streams
+        for k in env:
+            monkeypatch.delenv(k)
+        return l, g, n
+    l0, g0, n0 = run({})
+    assert n0 == 4
+    for env, nstreams in (({"STLPOSE_WGRAD_STREAMS": "0"}, 4), ({"STLPOSE_WGRAD_STREAMS": "1"}, 8),
+                          ({"STLPOSE_WGRAD_STREAMS": "n2", "STLPOSE_WGRAD_LAG": "5"}, 6), ({"STLPOSE_BALANCE": "all"}, 4),
+                          ({"STLPOSE_BALANCE_EXCHANGE": "1"}, 4)):
+        l1, g1, n1 = run(env)
+        assert n1 == nstreams, (env, n1)
+        assert l1 == l0, env
+        assert float((g1 - g0).abs().max()) <= 1e-5 * float(g0.abs().max()), env
