@@ -75,6 +75,33 @@ def fliplr_joints(joints, joints_vis, width, matched_parts=FLIP_PAIRS):
     return joints * joints_vis, joints_vis
 
 
+UPPER_BODY_IDS = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10)   # COCO: head, shoulders, arms (reference HRNet_Coco dataset)
+
+
+def half_body_transform(joints, joints_vis, aspect_ratio: float, upper_body_ids=UPPER_BODY_IDS, pixel_std: float = 200.0,
+                        rng=np.random):
+    """data/JointsDataset.py:75-130: pick the visible upper- or lower-body joints (one ``rng.randn()`` draw, like the
+    reference) and return the (center, scale) of their bounding box, widened to the crop's aspect ratio and by 1.5;
+    (None, None) when fewer than two joints are left."""
+    upper, lower = [], []
+    for jid in range(joints.shape[0]):
+        if joints_vis[jid][0] > 0:
+            (upper if jid in upper_body_ids else lower).append(joints[jid])
+    sel = upper if (rng.randn() < 0.5 and len(upper) > 2) else lower
+    if len(sel) < 2:
+        return None, None
+    sel = np.array(sel, dtype=np.float32)
+    center = sel.mean(axis=0)[:2]
+    lt, rb = np.amin(sel, axis=0), np.amax(sel, axis=0)
+    w, h = rb[0] - lt[0], rb[1] - lt[1]
+    if w > aspect_ratio * h:
+        h = w * 1.0 / aspect_ratio
+    elif w < aspect_ratio * h:
+        w = h * aspect_ratio
+    scale = np.array([w * 1.0 / pixel_std, h * 1.0 / pixel_std], dtype=np.float32) * 1.5
+    return center, scale
+
+
 def crop_batch(images: Sequence[torch.Tensor], centers, scales, rots, flips, image_size: Sequence[int],
                normalize: bool = True, device=None) -> Tuple[torch.Tensor, np.ndarray]:
     """JointsDataset.py:183-200 for a batch: images = uint8 HWC RGB tensors (any sizes); centers (B,2), scales (B,2)

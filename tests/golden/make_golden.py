@@ -512,8 +512,27 @@ def gen_g11():
         tj.append(np.stack([ref_tf.affine_transform(joints[i, k, 0:2], t) for k in range(17)]))
     fx.update(joints=joints, joints_vis=vis, widths=widths, flipped_joints=np.stack(fj), flipped_vis=np.stack(fv),
               transformed_joints=np.stack(tj))
+    # half-body augmentation: JointsDataset.half_body_transform on a stand-in self (the class file is loaded directly,
+    # like G9), numpy's global generator seeded per case so that the one randn() draw is reproducible
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_joints_dataset_hb", os.path.join(REF, "data", "JointsDataset.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    me = types.SimpleNamespace(num_joints=17, upper_body_ids=(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10), aspect_ratio=192.0 / 256.0, pixel_std=200)
+    hb_c, hb_s, hb_ok = [], [], []
+    for i in range(n):
+        np.random.seed(500 + i)
+        c, s = mod.JointsDataset.half_body_transform(me, joints[i].copy(), vis[i].copy())
+        hb_ok.append(c is not None)
+        hb_c.append(np.zeros(2) if c is None else np.asarray(c, np.float64))
+        hb_s.append(np.zeros(2) if s is None else np.asarray(s, np.float64))
+    vis_few = np.zeros((17, 3))
+    vis_few[12, :2] = 1       # a single visible joint -> (None, None)
+    np.random.seed(77)
+    c, s = mod.JointsDataset.half_body_transform(me, joints[0].copy(), vis_few)
+    fx.update(hb_center=np.stack(hb_c), hb_scale=np.stack(hb_s), hb_ok=np.array(hb_ok), hb_few_none=np.array(c is None and s is None))
     np.savez_compressed(os.path.join(HERE, "g11_affine.npz"), **fx)
-    print("G11 done", fx["trans_0"][2])
+    print("G11 done", fx["trans_0"][2], "half-body ok", hb_ok)
 
 
 if __name__ == "__main__":

@@ -38,3 +38,19 @@ def test_warp_oracle_identity_shift_and_flip():
     half = np.array([[1.0, 0, 0.5], [0, 1.0, 0]])             # half-pixel shift: average of horizontal neighbours
     out = pose_ref.warp_affine_bilinear(img, half, (30, 20))
     np.testing.assert_allclose(out[:, 1:], 0.5 * (img[:, :-1].astype(np.float32) + img[:, 1:]), rtol=0, atol=1e-4)
+
+
+def test_half_body_transform_matches_reference(golden_dir):
+    """JointsDataset.half_body_transform (data/JointsDataset.py:75-130), numpy's global generator seeded like the fixture."""
+    g = np.load(os.path.join(golden_dir, "g11_affine.npz"))
+    for i in range(len(g["rots"])):
+        np.random.seed(500 + i)
+        c, s = augment.half_body_transform(g["joints"][i].copy(), g["joints_vis"][i].copy(), 192.0 / 256.0)
+        assert (c is not None) == bool(g["hb_ok"][i])
+        if c is not None:
+            np.testing.assert_allclose(c, g["hb_center"][i], rtol=1e-7)
+            np.testing.assert_allclose(s, g["hb_scale"][i], rtol=1e-7)
+    vis_few = np.zeros((17, 3))
+    vis_few[12, :2] = 1
+    np.random.seed(77)
+    assert augment.half_body_transform(g["joints"][0].copy(), vis_few, 0.75) == (None, None) and bool(g["hb_few_none"])
