@@ -156,12 +156,22 @@ def extra_fp32_path(arch, batch, H, W, dev, steps=6, warmup=2):
                               note="whole step against the fp32-input MFMA peak (v_mfma_f32_16x16x4_f32)"))
 
 
+def _he_weights(convs, seed):
+    """Synthetic He-normal weights under torchvision's key names (no checkpoint, no network): (features idx, cin, cout)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for idx, cin, cout in convs:
+        out[f"features.{idx}.weight"] = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+        out[f"features.{idx}.bias"] = torch.randn(cout, generator=g) * 0.05
+    return out
+
+
 def extra_vgg_cfg4(dev, reps=5):
     """BASELINE configs[3] as far as the reference defines it (V1): VGG16 perceptual loss forward, batch 16,
     3 x 512 x 512, fp32, resize=False = 2 x 16 images through features[:23] (145.9 GFLOP per image and pass)."""
-    from oracle import vgg_ref
     from stlpose_amd import VGGPerceptualLoss
-    w = vgg_ref.synth_vgg_weights()
+    from stlpose_amd.vgg import VGG16_LAYOUT
+    w = _he_weights([(idx, ci, co) for _, idx, ci, co, _ in VGG16_LAYOUT], 16)
     g = torch.Generator().manual_seed(16)
     a = torch.rand(16, 3, 512, 512, generator=g)
     b = (a + 0.2 * torch.randn(16, 3, 512, 512, generator=g)).clamp_(0, 1)
@@ -181,7 +191,8 @@ def extra_vgg_cfg4(dev, reps=5):
         res[dt_name] = dict(ms_per_loss=round(dt * 1e3, 3), pairs_per_sec=round(16 / dt, 2), loss=float(loss.item()),
                             roofline=dict(bound="mfma", achieved=round(tf, 2), peak=peak, unit="TFLOP/s", frac=round(tf / peak, 4), traffic=None))
         del m
-    # CPU baseline: the oracle on 2 pairs (bounded sample of the same workload)
+    # CPU baseline: the oracle on 2 pairs (bounded sample of the same workload); the only use of oracle/ in this leg
+    from oracle import vgg_ref
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     t0 = time.time()
     with torch.no_grad():
@@ -196,9 +207,8 @@ def extra_vgg19_style(dev, reps=3):
     """BASELINE configs[3] by name: VGG19 content + Gram style loss forward, 512 x 512, batch 16 (stylised, content and
     style batches = 48 images through conv1_1 .. conv5_1 + 160 Gram launches).  V2 has no reference item: parity
     unpinned (oracle = published-method restatement)."""
-    from oracle import vgg_ref
-    from stlpose_amd.vgg19_style import VGG19StyleLoss, vgg19_flops_per_image
-    w = vgg_ref.synth_vgg19_weights()
+    from stlpose_amd.vgg19_style import VGG19_LAYOUT, VGG19StyleLoss, vgg19_flops_per_image
+    w = _he_weights([(idx, ci, co) for idx, ci, co, _ in VGG19_LAYOUT], 19)
     g = torch.Generator().manual_seed(19)
     x, c, s_ = (torch.rand(16, 3, 512, 512, generator=g) for _ in range(3))
     fl = 48 * vgg19_flops_per_image(512, 512)
@@ -218,6 +228,7 @@ def extra_vgg19_style(dev, reps=3):
                             roofline=dict(bound="mfma", achieved=round(tf, 2), peak=peak, unit="TFLOP/s", frac=round(tf / peak, 4), traffic=None))
         del m
         torch.cuda.empty_cache()
+    from oracle import vgg_ref   # CPU baseline only
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     t0 = time.time()
     with torch.no_grad():

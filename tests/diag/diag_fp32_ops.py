@@ -1,7 +1,7 @@
 """Diagnostic: fp32-path accuracy of the unit ops against fp64 references (where do the ~1e-3 gradient errors of the
 fp32 network come from?)."""
 import ctypes as C, math, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.nn.functional as F
 from stlpose_amd import capi
 from stlpose_amd.engine import choose_tile

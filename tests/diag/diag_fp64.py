@@ -1,6 +1,6 @@
 """Diagnostic: is the B=32 fp32 gradient deviation rounding?  Oracle in fp64 vs oracle fp32 vs HIP fp32."""
 import os, sys, time, re
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import hrnet_ref, pose_ref
 from tests.golden.make_golden import synth_batch, FULL_GRAD_KEYS

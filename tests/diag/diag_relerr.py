@@ -1,6 +1,6 @@
 """Diagnostic: run the fp32 unit tests of tests/test_ops_gpu.py and print the LARGEST relerr each one saw."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import tests.test_ops_gpu as T
 
 seen = []

@@ -1,6 +1,6 @@
 """Diagnostic: per-parameter gradient error of the fp32 HIP path vs an fp64 oracle, in backward order (tiny net)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import hrnet_ref, pose_ref
 from tests.golden.make_golden import synth_batch
