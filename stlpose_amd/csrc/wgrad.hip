@@ -3,12 +3,12 @@
 // GEMM view: M = 32 output channels, N = 32 input channels per tap, K = output pixels.
 // Both operands are K-major in memory (NHWC), so fragments are read TRANSPOSED from LDS:
 // ds_read_b64_tr_b16 for bf16, plain 4-byte reads for fp32 (one element per lane per MFMA).
-// Each of the 4 waves takes a quarter of the tile's pixels (its own K range) and keeps all
-// 2x2xTAPS 16x16 accumulators in registers across the block's tiles; the block reduces its
-// waves through LDS once and writes one fp32 slab [Co][taps][Ci] (deterministic split-K;
-// slabs are summed by stl_reduce_slabs).
-// Pipeline: the global loads of tile t+1 are issued (unconditionally, clamped addresses) before
-// the MFMAs of tile t and written to LDS after them; index arithmetic is hoisted out of the loop.
+// Each of the 4 waves owns one 16x16 quadrant of the block's 32x32 channels for all taps (4 x taps accumulator
+// registers) and multiplies every pixel of every tile of the block; the block writes one fp32 slab
+// [Co][taps][Ci] (deterministic split-K over blocks; slabs are summed by stl_reduce_slabs).
+// Pipeline: two register sets of staged loads -- the global loads of tile t+2 are issued (unconditionally,
+// clamped addresses) before the MFMAs of tile t; index arithmetic is hoisted out of the loop.
+#include <type_traits>
 #include "common.cuh"
 
 namespace {
@@ -28,8 +28,6 @@ struct WgK {
     int tiles_c, npt, HR, HC, HP, PI, pad, taps;
     int psg, psh;  // LDS bytes per pixel (32 channels + 16 B pad)
     int off_cg, off_ch, off_g, off_h;
-    int grp_stride;  // NG = 2: byte distance between the two wave groups' LDS tiles
-    int quad;        // NG = 1: cross-wave reduction quadrant by quadrant (small LDS footprint)
     float r_TW, r_HC, r_tc, r_vp, r_PI;  // reciprocals for fdiv
 };
 
@@ -61,34 +59,64 @@ __device__ __forceinline__ V16 frag_tr<float>(const char* base, const int* rowof
     return v;
 }
 
+// Same fragments from per-lane LDS byte addresses (lane term and row offset folded in) plus a compile-time offset:
+// with the address register opaque to the optimiser inside the tile loop the offset lands in the instruction's
+// immediate field (otherwise LLVM hoists one address register PER READ out of the loop: 36 VGPRs for 3x3).
+template <typename T>
+__device__ __forceinline__ V16 frag_at(const uint32_t* addr, int off);
+template <>
+__device__ __forceinline__ V16 frag_at<__bf16>(const uint32_t* addr, int off) {
+    V16 v;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)(addr[h] + off));
+        const uint64_t bits = __builtin_bit_cast(uint64_t, r);
+        v.w[2 * h] = (uint32_t)bits;
+        v.w[2 * h + 1] = (uint32_t)(bits >> 32);
+    }
+    return v;
+}
+template <>
+__device__ __forceinline__ V16 frag_at<float>(const uint32_t* addr, int off) {
+    V16 v;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v.w[s] = *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(addr[s] + off);
+    return v;
+}
+
 // NVH: h (input halo) staging vectors per thread; GQ: g is BNBWD (second tensor on load)
-// OCC: blocks per CU the register budget is sized for (2 only where it does not spill)
-// NG: wave groups per block.  NG = 2: two groups of 4 waves, each with its OWN LDS tiles and its own tile sequence
-// (tile 2i + group of the block), under block-wide barriers.  The K loop of a group is a chain of memory round
-// trips (load -> transform -> LDS -> barrier -> 36 MFMAs), ~2 us per 128 pixels for 0.3 us of matrix work; two
-// groups keep twice the bytes in flight per CU and halve the number of round trips per block, WITHOUT doubling the
-// split-K slabs the way a second block per CU would (one slab per block, 8 waves reduced in fixed order).
-template <typename T, int KS, int NVH, bool GQ, int TPX, int OCC, int NG = 1>
-__global__ __launch_bounds__(256 * NG, OCC) void wgrad_kernel(const WgK k) {
+// OCC: blocks per CU the register budget is sized for
+//
+// Work split: wave w owns ONE 16 x 16 quadrant (mt = w >> 1, nt = w & 1) of the block's 32 x 32 channels for ALL taps
+// and ALL pixels of every tile (M/N split).  The earlier K split (each wave a quarter of the pixels, all four
+// quadrants) needed 144 accumulator registers per lane and a cross-wave reduction through LDS at the end; this one
+// needs 4 * TAPS = 36, no reduction, and leaves room for TWO tiles of staged loads per thread: the loads of tile
+// t + 2 are issued while tile t is multiplied, so a tile's memory round trip (~2 us when 256 blocks load at once)
+// is covered by two iterations instead of being exposed once per tile (it was ~80 % of the K loop).
+template <typename T, int KS, int NVH, bool GQ, int TPX, int OCC>
+__global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgK k) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KV = ET<T>::KV, TAPS = KS * KS;
     constexpr int KSTEP = 4 * KV;               // pixels per MFMA K step (32 bf16 / 16 f32)
     constexpr int NR = sizeof(T) == 2 ? 2 : 4;  // row offsets a lane needs per fragment
     constexpr int VPX = 32 / KV;                // 16-byte vectors per pixel (32 channels)
     constexpr int NVG = TPX * VPX / 256;        // g staging vectors per thread
+    constexpr int PS = 32 * (int)sizeof(T) + 16;  // LDS bytes per pixel (== k.psg == k.psh): compile-time, so that tap and
+                                                  // K-step offsets of the fragment reads are instruction immediates
+    constexpr int NKT = TPX / KSTEP;            // K steps per tile
     const stl_wgrad& p = k.p;
-    const int ftid = threadIdx.x, tid = ftid & 255, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-    const int grp = NG == 1 ? 0 : __builtin_amdgcn_readfirstlane(ftid >> 8);   // wave group (block-local tile stream)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const int mt = wave >> 1, nt = wave & 1;
     const int co0 = blockIdx.y * 32, ci0 = blockIdx.z * 32;
     WSTAMP(0);
     float* cgc = reinterpret_cast<float*>(smem + k.off_cg);  // [3][32]
     float* chc = reinterpret_cast<float*>(smem + k.off_ch);  // [2][32]
-    char* sG = smem + k.off_g + grp * k.grp_stride;
-    char* sH = smem + k.off_h + grp * k.grp_stride;
+    char* sG = smem + k.off_g;
+    char* sH = smem + k.off_h;
 
     const int tilepx = p.TH * p.TW;
     const int vpitch = p.Ho + 1;
-    const int nks = (tilepx + KSTEP - 1) / KSTEP;
+    const int hrow = k.HC * PS;   // LDS bytes per halo row
 
     // ---- loop-invariant staging descriptors
     int g_yx[NVG];  // (ty << 16) | tx of the tile pixel of slot i, -1 = beyond the tile (zero row)
@@ -114,127 +142,148 @@ __global__ __launch_bounds__(256 * NG, OCC) void wgrad_kernel(const WgK k) {
     }
     const bool g_chok = (co0 + g_part * KV) < p.Co, h_chok = (ci0 + g_part * KV) < p.Ci;
 
-    // ---- MFMA-side offsets for this wave's K steps (tile geometry is the same for every tile)
-    // K steps per wave: TPX px / KSTEP / 4 waves (128 px: 1 for bf16, 2 for fp32; 256 px bf16: 2)
-    constexpr int NKS = (TPX / KSTEP + 3) / 4;
-    int rg[NKS][NR], rh[NKS][NR];
+    // ---- fragment-read addresses (LDS byte addresses, lane term and this wave's quadrant folded in).  g rows are
+    // linear in the K step (row = s * KSTEP + c), so one base per row register; h rows follow the tile geometry.
+    const uint32_t lterm = sizeof(T) == 2 ? (lane & 3) * 8 : (lane & 15) * 4;
+    uint32_t gaw[NR], hbw[NKT][NR];
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-        const int kb = (wave + 4 * s) * KSTEP;
+    for (int i = 0; i < NR; ++i) {
+        const int c = sizeof(T) == 2 ? 8 * g + 4 * i + ((lane & 15) >> 2) : 4 * g + i;
+        gaw[i] = (uint32_t)(uintptr_t)sG + c * PS + lterm + mt * 16 * (int)sizeof(T);
 #pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            int m;
-            if constexpr (sizeof(T) == 2)
-                m = kb + 8 * g + 4 * i + ((lane & 15) >> 2);
-            else
-                m = kb + 4 * g + i;
-            if (m > TPX - 1) m = TPX - 1;
-            rg[s][i] = m * k.psg;  // rows >= tilepx are zero-filled in sG
-            if (m >= tilepx) m = 0;
+        for (int s = 0; s < NKT; ++s) {
+            int m = s * KSTEP + c;
+            if (m >= tilepx) m = 0;   // rows >= tilepx are zero in sG: any valid h row will do
             const int ty = fdiv(m, k.r_TW), tx = m - ty * p.TW;
-            rh[s][i] = ((ty * p.stride) * k.HC + tx * p.stride) * k.psh;
+            hbw[s][i] = (uint32_t)(uintptr_t)sH + ((ty * p.stride) * k.HC + tx * p.stride) * PS + lterm + nt * 16 * (int)sizeof(T);
         }
     }
 
-    V16 rgv[NVG], rgq[GQ ? NVG : 1], rhv[NVH];
-    int g_go[NVG], h_go[NVH];
+    // ---- two register sets of staged loads
+    V16 rgv[2][NVG], rgq[2][GQ ? NVG : 1], rhv[2][NVH];
+    uint32_t okm[2] = {0u, 0u};   // validity bits of a set: bit i = g slot i, bit NVG + i = h slot i
 
-    auto setup = [&](int t) {
+    // unconditional loads (a guarded load would be serialised by the compiler); invalid slots read element 0 and
+    // are zeroed when written to LDS
+    auto fetch = [&](auto SET, int t) __attribute__((always_inline)) {
+        constexpr int S = decltype(SET)::value;
         const int tr = fdiv(t, k.r_tc), tc = t - tr * k.tiles_c;
         const int vr0 = tr * p.TH, c0 = tc * p.TW;
         const int gb0 = fdiv(vr0, k.r_vp), gy0 = vr0 - gb0 * vpitch;
+        uint32_t ok = 0;
 #pragma unroll
         for (int i = 0; i < NVG; ++i) {
-            g_go[i] = -1;
+            int go = -1;
             if (g_yx[i] >= 0 && g_chok) {
                 int oy = gy0 + (g_yx[i] >> 16), b = gb0;
                 const int c = c0 + (g_yx[i] & 0xffff);
                 while (oy >= vpitch) oy -= vpitch, ++b;
-                if (b < p.B && oy < p.Ho && c < p.Wo) g_go[i] = ((b * p.Ho + oy) * p.Wo + c) * p.Co + co0 + g_part * KV;
+                if (b < p.B && oy < p.Ho && c < p.Wo) go = ((b * p.Ho + oy) * p.Wo + c) * p.Co + co0 + g_part * KV;
             }
+            const size_t off = go >= 0 ? (size_t)go : 0;
+            ok |= go >= 0 ? 1u << i : 0u;
+            rgv[S][i] = ldg16((const char*)p.g.x + off * sizeof(T));
+            if (GQ) rgq[S][i] = ldg16((const char*)p.g.y + off * sizeof(T));
         }
         const int vrs = vr0 * p.stride, cb = c0 * p.stride - k.pad;
         const int hb0 = fdiv(vrs, k.r_PI), hy0 = vrs - hb0 * k.PI - k.pad;
 #pragma unroll
         for (int i = 0; i < NVH; ++i) {
-            h_go[i] = -1;
+            int ho = -1;
             if (h_rc[i] >= 0 && h_chok) {
                 int iy = hy0 + (h_rc[i] >> 16), b = hb0;
                 const int ix = cb + (h_rc[i] & 0xffff);
                 if (iy >= 0 && ix >= 0 && ix < p.Wi) {
                     while (iy >= k.PI) iy -= k.PI, ++b;
-                    if (b < p.B && iy < p.Hi) h_go[i] = ((b * p.Hi + iy) * p.Wi + ix) * p.Ci + ci0 + g_part * KV;
+                    if (b < p.B && iy < p.Hi) ho = ((b * p.Hi + iy) * p.Wi + ix) * p.Ci + ci0 + g_part * KV;
                 }
             }
+            const size_t off = ho >= 0 ? (size_t)ho : 0;
+            ok |= ho >= 0 ? 1u << (NVG + i) : 0u;
+            rhv[S][i] = ldg16((const char*)p.h.x + off * sizeof(T));
         }
-    };
-    // unconditional loads (a guarded load would be serialised by the compiler); invalid slots read
-    // element 0 and are zeroed when written to LDS
-    auto issue = [&](bool en) {
-#pragma unroll
-        for (int i = 0; i < NVG; ++i) {
-            const size_t off = (en && g_go[i] >= 0) ? (size_t)g_go[i] : 0;
-            rgv[i] = ldg16((const char*)p.g.x + off * sizeof(T));
-            if (GQ) rgq[i] = ldg16((const char*)p.g.y + off * sizeof(T));
-        }
-#pragma unroll
-        for (int i = 0; i < NVH; ++i) {
-            const size_t off = (en && h_go[i] >= 0) ? (size_t)h_go[i] : 0;
-            rhv[i] = ldg16((const char*)p.h.x + off * sizeof(T));
-        }
+        okm[S] = ok;
     };
     const float relu_lo = p.h.relu ? 0.f : -INFINITY;
-    auto write_lds = [&]() {
+    auto write_lds = [&](auto SET) __attribute__((always_inline)) {
+        constexpr int S = decltype(SET)::value;
         const int cl = g_part * KV;
 #pragma unroll
         for (int i = 0; i < NVG; ++i) {
-            V16 val = rgv[i];
-            if (GQ) val = xform_bnbwd<T>(val, rgq[i], cgc + cl, cgc + 32 + cl, cgc + 64 + cl);
-            mask16(val, g_go[i] >= 0);
+            V16 val = rgv[S][i];
+            if (GQ) val = xform_bnbwd<T>(val, rgq[S][i], cgc + cl, cgc + 32 + cl, cgc + 64 + cl);
+            mask16(val, (okm[S] >> i) & 1u);
             const int v = tid + i * 256;
-            *reinterpret_cast<V16*>(sG + (v / VPX) * k.psg + g_part * 16) = val;
+            *reinterpret_cast<V16*>(sG + (v / VPX) * PS + g_part * 16) = val;
         }
 #pragma unroll
         for (int i = 0; i < NVH; ++i) {
             if (h_rc[i] < 0) continue;
-            V16 val = rhv[i];
+            V16 val = rhv[S][i];
             if (p.h.mode == STL_SRC_BN) val = xform_bn<T>(val, chc + cl, chc + 32 + cl, relu_lo);
-            mask16(val, h_go[i] >= 0);
+            mask16(val, (okm[S] >> (NVG + i)) & 1u);
             const int v = tid + i * 256;
-            *reinterpret_cast<V16*>(sH + (v / VPX) * k.psh + g_part * 16) = val;
+            *reinterpret_cast<V16*>(sH + (v / VPX) * PS + g_part * 16) = val;
         }
     };
 
-    f32x4 acc[2][2][TAPS];
+    f32x4 acc[TAPS];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int t = 0; t < TAPS; ++t) acc[a][b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < TAPS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int t = blockIdx.x + grp * gridDim.x;    // group g takes tiles blockIdx.x + (NG * i + g) * gridDim.x
-    bool have = t < k.npt;
-    bool more = blockIdx.x < k.npt;          // block-uniform loop condition (group 0 has a tile whenever any group has)
+    // all pixels of the staged tile x this wave's quadrant x all taps.  Fragment reads run PF (tap, K step) pairs
+    // ahead of their MFMA through a register ring; the address registers are made opaque inside the loop so that
+    // LLVM folds the tap / K-step offsets into the instructions instead of hoisting one address register per read.
+    auto mfma_tile = [&]() __attribute__((always_inline)) {
+        constexpr int NJ = NKT * TAPS, PF = KS == 3 ? 6 : 2;
+        uint32_t ga[NR], hb[NKT][NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            ga[i] = gaw[i];
+            asm volatile("" : "+v"(ga[i]));
+#pragma unroll
+            for (int s = 0; s < NKT; ++s) {
+                hb[s][i] = hbw[s][i];
+                asm volatile("" : "+v"(hb[s][i]));
+            }
+        }
+        V16 aq[2], bq[PF];
+        auto bfrag = [&](int j) __attribute__((always_inline)) {
+            const int s = j / TAPS, tap = j % TAPS;
+            uint32_t ad[NR];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) ad[i] = hb[s][i] + (tap / KS) * hrow;
+            return frag_at<T>(ad, (tap % KS) * PS);
+        };
+        aq[0] = frag_at<T>(ga, 0);
+#pragma unroll
+        for (int j = 0; j < PF - 1 && j < NJ; ++j) bq[j] = bfrag(j);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int s = j / TAPS, tap = j % TAPS;
+            if (tap == 0 && s + 1 < NKT) aq[(s + 1) & 1] = frag_at<T>(ga, (s + 1) * KSTEP * PS);
+            if (j + PF - 1 < NJ) bq[(j + PF - 1) % PF] = bfrag(j + PF - 1);
+            mma16<T>(acc[tap], aq[s & 1], bq[j % PF]);
+        }
+    };
+
+    const int step = gridDim.x;
+    int t = blockIdx.x;
     WSTAMP(1);
-    // BatchNorm constants (wave 3 of group 0: lanes 0-31 those of g, 32-63 those of h): the statistics loads are
-    // issued ahead of the first tile's loads, the arithmetic runs while those are in flight
+    // BatchNorm constants (wave 3: lanes 0-31 those of g, 32-63 those of h): the statistics loads are issued ahead
+    // of the first tiles' loads, the arithmetic runs while those are in flight
     SrcRaw raw;
-    const bool cw = wave == 3 && grp == 0, cg = lane < 32;
+    const bool cw = wave == 3, cg = lane < 32;
     const int cch = lane & 31;
     const bool cok = cw && (cg ? co0 + cch < p.Co : ci0 + cch < p.Ci);
     if (cok) {
         if (cg) src_raw_load(p.g, co0 + cch, p.Co, raw);
         else src_raw_load(p.h, ci0 + cch, p.Ci, raw);
     }
-    if (have) setup(t);
-    else {
-#pragma unroll
-        for (int i = 0; i < NVG; ++i) g_go[i] = -1;
-#pragma unroll
-        for (int i = 0; i < NVH; ++i) h_go[i] = -1;
-    }
-    issue(have);
+    constexpr std::integral_constant<int, 0> I0{};
+    constexpr std::integral_constant<int, 1> I1{};
+    if (t < k.npt) fetch(I0, t);
+    if (t + step < k.npt) fetch(I1, t + step);
     WSTAMP(2);
     if (cw) {
         float a = 0.f, b = 0.f, cc = 0.f;
@@ -248,155 +297,48 @@ __global__ __launch_bounds__(256 * NG, OCC) void wgrad_kernel(const WgK k) {
     __syncthreads();  // constants visible
     WSTAMP(3);
     bool first = true;
-
-    int t0 = blockIdx.x;   // group 0's tile of this iteration (loop control)
-    while (more) {
-        write_lds();   // a group without a tile writes zeros (every g_go / h_go is -1)
+    auto body = [&](auto SET) __attribute__((always_inline)) {
+        write_lds(SET);
         __syncthreads();
         if (first) WSTAMP(4);
-        const int tn = t + NG * gridDim.x;
-        const bool have_n = tn < k.npt;
-        if (have_n) setup(tn);
-        else if (NG > 1) {
-#pragma unroll
-            for (int i = 0; i < NVG; ++i) g_go[i] = -1;
-#pragma unroll
-            for (int i = 0; i < NVH; ++i) h_go[i] = -1;
-        }
-        issue(have_n);  // next tile's loads fly during the MFMAs
-        if (have) {
-#pragma unroll
-            for (int s = 0; s < NKS; ++s) {
-                if (wave + 4 * s < nks) {
-                    V16 a[2];
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) a[mt] = frag_tr<T>(sG, rg[s], mt * 16 * (int)sizeof(T), lane);
-#pragma unroll
-                    for (int tap = 0; tap < TAPS; ++tap) {
-                        const int toff = ((tap / KS) * k.HC + (tap % KS)) * k.psh;
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
-                            const V16 b = frag_tr<T>(sH + toff, rh[s], nt * 16 * (int)sizeof(T), lane);
-#pragma unroll
-                            for (int mt = 0; mt < 2; ++mt) mma16<T>(acc[mt][nt][tap], a[mt], b);
-                        }
-                    }
-                }
-            }
-        }
+        if (t + 2 * step < k.npt) fetch(SET, t + 2 * step);   // block-uniform: two tiles ahead, into the set just drained
+        mfma_tile();
         __syncthreads();
         if (first) WSTAMP(5);
         first = false;
-        t = tn, have = have_n;
-        t0 += NG * gridDim.x;
-        more = t0 < k.npt;
+        t += step;
+    };
+    while (t < k.npt) {
+        body(I0);
+        if (t >= k.npt) break;
+        body(I1);
     }
     WSTAMP(6);
-    if (NG == 1 && k.quad) {
-        // ---- reduce the 4 waves QUADRANT BY QUADRANT through a small LDS region, fixed order (w0+w2)+(w1+w3):
-        // deterministic.  One quadrant = (mt, nt): TAPS tiles per wave.  The whole-accumulator version needs
-        // 2 x 36.9 KB of LDS (more than the staging tiles), which is what a co-resident conv block cannot use;
-        // per quadrant it is 2 x 9.2 KB for four more barrier pairs.
-        f32x4* red = reinterpret_cast<f32x4*>(smem + k.off_g);
-        constexpr int RQ = TAPS * 64;  // f32x4 per region (one quadrant of one wave)
+    {   // every wave writes its quadrant of the block's slab [Co][taps][Ci]
         float* slab = p.partial + (size_t)blockIdx.x * p.Co * TAPS * p.Ci;
+        const int ci = ci0 + nt * 16 + (lane & 15), co = co0 + mt * 16 + 4 * g;
+        float* dst = slab + (size_t)co * TAPS * p.Ci + ci;
+        if (ci < p.Ci) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int mt = q >> 1, nt = q & 1;
-            f32x4* mine = red + (wave & 1) * RQ + lane;
-            if (wave >= 2) {
+            for (int tap = 0; tap < TAPS; ++tap)
 #pragma unroll
-                for (int tap = 0; tap < TAPS; ++tap) mine[tap * 64] = acc[mt][nt][tap];
-            }
-            __syncthreads();
-            if (wave < 2) {
-#pragma unroll
-                for (int tap = 0; tap < TAPS; ++tap) mine[tap * 64] = acc[mt][nt][tap] + mine[tap * 64];
-            }
-            __syncthreads();
-            {   // all four waves write the quadrant: wave w takes taps w, w + 4, w + 8
-                const int ci = ci0 + nt * 16 + (lane & 15), co = co0 + mt * 16 + 4 * g;
-                float* dst = slab + (size_t)co * TAPS * p.Ci + ci;
-                const bool ciok = ci < p.Ci;
-#pragma unroll
-                for (int tt = 0; tt < (TAPS + 3) / 4; ++tt) {
-                    const int tap = wave + 4 * tt;
-                    if (tap < TAPS) {
-                        const f32x4 v = red[tap * 64 + lane] + red[RQ + tap * 64 + lane];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (ciok && co + r < p.Co) dst[((size_t)r * TAPS + tap) * p.Ci] = v[r];
-                    }
-                }
-            }
-            if (q < 3) __syncthreads();   // the region is rewritten by the next quadrant
-        }
-        WSTAMP(7);
-    } else {
-        // ---- reduce the waves through 2 * NG LDS regions in fixed order ((w0+w2)+(w1+w3) per group, then group 0 +
-        // group 1: deterministic), then every wave writes part of one (mt, nt) quadrant of the block's slab.
-        // region layout: [tile = (mt*2+nt)*TAPS+tap][lane] f32x4 -> conflict-free 16-byte accesses
-        f32x4* red = reinterpret_cast<f32x4*>(smem + k.off_g);
-        constexpr int RT = 4 * TAPS * 64;  // f32x4 per region
-        {
-            f32x4* mine = red + (grp * 2 + (wave & 1)) * RT + lane;
-            if (wave >= 2) {
-    #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-    #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-    #pragma unroll
-                        for (int tap = 0; tap < TAPS; ++tap) mine[((mt * 2 + nt) * TAPS + tap) * 64] = acc[mt][nt][tap];
-            }
-            __syncthreads();
-            if (wave < 2) {
-    #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-    #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-    #pragma unroll
-                        for (int tap = 0; tap < TAPS; ++tap) {
-                            f32x4* d = mine + ((mt * 2 + nt) * TAPS + tap) * 64;
-                            *d = acc[mt][nt][tap] + *d;
-                        }
-            }
-            __syncthreads();
-        }
-        WSTAMP(7);
-        {
-            float* slab = p.partial + (size_t)blockIdx.x * p.Co * TAPS * p.Ci;
-            const int mt = wave >> 1, nt = wave & 1;
-            const int ci = ci0 + nt * 16 + (lane & 15), co = co0 + mt * 16 + 4 * g;
-            const f32x4* src = red + (wave * TAPS) * 64 + lane;
-            float* dst = slab + (size_t)co * TAPS * p.Ci + ci;
-            const bool ciok = ci < p.Ci;
-            constexpr int TSPLIT = NG == 1 ? TAPS : (TAPS + 1) / 2;   // NG = 2: group 0 writes taps [0, TSPLIT), group 1 the rest
-    #pragma unroll
-            for (int tt = 0; tt < TSPLIT; ++tt) {
-                const int tap = tt + grp * TSPLIT;
-                if (tap < TAPS) {
-                    f32x4 v = src[tap * 64] + src[RT + tap * 64];
-                    if constexpr (NG == 2) v = v + (src[2 * RT + tap * 64] + src[3 * RT + tap * 64]);
-    #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (ciok && co + r < p.Co) dst[((size_t)r * TAPS + tap) * p.Ci] = v[r];
-                }
-            }
+                for (int r = 0; r < 4; ++r)
+                    if (co + r < p.Co) dst[((size_t)r * TAPS + tap) * p.Ci] = acc[tap][r];
         }
     }
     WSTAMP(8);
 }
 
-template <typename T, int KS, int NVH, bool GQ, int TPX = 128, int NG = 1>
+template <typename T, int KS, int NVH, bool GQ, int TPX = 128>
 int launch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
-    constexpr int OCC = (NVH == 3 && TPX == 128 && sizeof(T) == 2) ? 2 : 1;
+    constexpr int OCC = (NVH <= 6 && TPX == 128 && sizeof(T) == 2) ? 2 : 1;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, KS, NVH, GQ, TPX, OCC, NG>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, KS, NVH, GQ, TPX, OCC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((wgrad_kernel<T, KS, NVH, GQ, TPX, OCC, NG>), grid, dim3(256 * NG), lds, st, k);
+    hipLaunchKernelGGL((wgrad_kernel<T, KS, NVH, GQ, TPX, OCC>), grid, dim3(256), lds, st, k);
     STL_LAUNCH_CHECK("conv_wgrad");
     return 0;
 }
@@ -682,10 +624,6 @@ int dispatch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
         }
         return stl_set_error("wgrad: 256-pixel tiles need bf16 and a halo of at most 384 pixels (have %d)", k.HP);
     }
-    if constexpr (sizeof(T) == 2) {   // bf16, 128-pixel tiles, small halo: two wave groups per block when the LDS layout was sized for them
-        if (nvh <= 3 && k.grp_stride > 0)
-            return gq ? launch<T, KS, 3, true, 128, 2>(k, grid, lds, st) : launch<T, KS, 3, false, 128, 2>(k, grid, lds, st);
-    }
     if (nvh <= 3) return gq ? launch<T, KS, 3, true>(k, grid, lds, st) : launch<T, KS, 3, false>(k, grid, lds, st);
     if (nvh <= 6) return gq ? launch<T, KS, 6, true>(k, grid, lds, st) : launch<T, KS, 6, false>(k, grid, lds, st);
     if (nvh <= 9) return gq ? launch<T, KS, 9, true>(k, grid, lds, st) : launch<T, KS, 9, false>(k, grid, lds, st);
@@ -749,27 +687,9 @@ extern "C" int stl_conv_wgrad(const stl_wgrad* pp, void* stream) {
     k.off_ch = 3 * 32 * 4;
     k.off_g = 1024;  // consts: g [3][32] floats at 0, h [2][32] floats at 384 -> 640 B used
     int szG = (p.TH * p.TW > 128 ? 256 : 128) * k.psg;
-    static const int quad_env = getenv("STL_WGRAD_RED_FULL") ? 0 : 1;
-    k.quad = quad_env;
-    // quadrant-wise reduction: two regions of [taps][64] f32x4; whole accumulators: two (NG = 2: four) of [4*taps][64]
-    int szRed = (k.quad ? 2 : 2 * 4) * k.taps * 64 * 16;
     int szH = k.HP * k.psh;
     k.off_h = k.off_g + szG;
     size_t lds = (size_t)k.off_h + szH;
-    k.grp_stride = 0;
-    {   // two wave groups (NG = 2): bf16, 128-pixel tiles, <= 3 h staging vectors per thread, enough tiles per block
-        // opt-in: isolated 27.1 -> 25.2 us per launch, but a 148 KB / 8-wave block owns its CU and the step gets
-        // SLOWER (19.1 -> 20.4 ms): co-residency with the data-gradient blocks matters more than the launch itself
-        static const int ng_env = getenv("STL_WGRAD_NG") ? atoi(getenv("STL_WGRAD_NG")) : 1;
-        const int nvh = ceil_div(k.HP * (32 / (p.dtype == STL_BF16 ? 8 : 4)), 256);
-        if (ng_env == 2 && p.dtype == STL_BF16 && p.TH * p.TW <= 128 && nvh <= 3 && k.npt >= 2 * p.nsplit) {
-            k.grp_stride = (szG + szH + 15) & ~15;
-            lds = (size_t)k.off_g + 2 * (size_t)k.grp_stride;
-            szRed = 4 * 4 * k.taps * 64 * 16;
-            k.quad = 0;
-        }
-    }
-    if ((size_t)k.off_g + szRed > lds) lds = (size_t)k.off_g + szRed;
     STL_CHECK(lds <= 160 * 1024, "wgrad: tile needs %zu B of LDS (>160 KiB)", lds);
     STL_CHECK(p.nsplit <= k.npt || p.nsplit == 1, "wgrad: nsplit %d > tiles %d", p.nsplit, k.npt);
     dim3 grid(p.nsplit, ceil_div(p.Co, 32), ceil_div(p.Ci, 32));
