@@ -93,20 +93,24 @@ __device__ __forceinline__ V16 frag_at<float>(const uint32_t* addr, int off) {
 // needs 4 * TAPS = 36, no reduction, and leaves room for TWO tiles of staged loads per thread: the loads of tile
 // t + 2 are issued while tile t is multiplied, so a tile's memory round trip (~2 us when 256 blocks load at once)
 // is covered by two iterations instead of being exposed once per tile (it was ~80 % of the K loop).
-template <typename T, int KS, int NVH, bool GQ, int TPX, int OCC>
-__global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgK k) {
+template <typename T, int KS, int NVH, bool GQ, int TPX, int OCC, int NW>
+__global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KV = ET<T>::KV, TAPS = KS * KS;
     constexpr int KSTEP = 4 * KV;               // pixels per MFMA K step (32 bf16 / 16 f32)
     constexpr int NR = sizeof(T) == 2 ? 2 : 4;  // row offsets a lane needs per fragment
     constexpr int VPX = 32 / KV;                // 16-byte vectors per pixel (32 channels)
-    constexpr int NVG = TPX * VPX / 256;        // g staging vectors per thread
+    constexpr int NT = 64 * NW;                 // threads per block
+    constexpr int NVG = TPX * VPX / NT;         // g staging vectors per thread
+    static_assert(NVG >= 1 && NVG * NT == TPX * VPX, "g staging slots must tile the block");
+    constexpr int NTG = NW / 4;                 // tap groups (NW = 8: waves 0-3 take taps 0..4, waves 4-7 taps 5..8)
+    constexpr int TPG = (TAPS + NTG - 1) / NTG; // taps per group (accumulators per wave)
     constexpr int PS = 32 * (int)sizeof(T) + 16;  // LDS bytes per pixel (== k.psg == k.psh): compile-time, so that tap and
                                                   // K-step offsets of the fragment reads are instruction immediates
     constexpr int NKT = TPX / KSTEP;            // K steps per tile
     const stl_wgrad& p = k.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-    const int mt = wave >> 1, nt = wave & 1;
+    const int mt = (wave & 3) >> 1, nt = wave & 1, tg = wave >> 2;
     const int co0 = blockIdx.y * 32, ci0 = blockIdx.z * 32;
     WSTAMP(0);
     float* cgc = reinterpret_cast<float*>(smem + k.off_cg);  // [3][32]
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgK k) {
     const int g_part = tid % VPX;
 #pragma unroll
     for (int i = 0; i < NVG; ++i) {
-        const int m = (tid + i * 256) / VPX;
+        const int m = (tid + i * NT) / VPX;
         g_yx[i] = -1;
         if (m < tilepx) {
             const int ty = fdiv(m, k.r_TW);
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgK k) {
     int h_rc[NVH];
 #pragma unroll
     for (int i = 0; i < NVH; ++i) {
-        const int v = tid + i * 256;
+        const int v = tid + i * NT;
         h_rc[i] = -1;
         if (v < k.HP * VPX) {
             const int hp = v / VPX, hr = fdiv(hp, k.r_HC);
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgK k) {
             V16 val = rgv[S][i];
             if (GQ) val = xform_bnbwd<T>(val, rgq[S][i], cgc + cl, cgc + 32 + cl, cgc + 64 + cl);
             mask16(val, (okm[S] >> i) & 1u);
-            const int v = tid + i * 256;
+            const int v = tid + i * NT;
             *reinterpret_cast<V16*>(sG + (v / VPX) * PS + g_part * 16) = val;
         }
 #pragma unroll
@@ -222,20 +226,21 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgK k) {
             V16 val = rhv[S][i];
             if (p.h.mode == STL_SRC_BN) val = xform_bn<T>(val, chc + cl, chc + 32 + cl, relu_lo);
             mask16(val, (okm[S] >> (NVG + i)) & 1u);
-            const int v = tid + i * 256;
+            const int v = tid + i * NT;
             *reinterpret_cast<V16*>(sH + (v / VPX) * PS + g_part * 16) = val;
         }
     };
 
-    f32x4 acc[TAPS];
+    f32x4 acc[TPG];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < TPG; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // all pixels of the staged tile x this wave's quadrant x all taps.  Fragment reads run PF (tap, K step) pairs
     // ahead of their MFMA through a register ring; the address registers are made opaque inside the loop so that
     // LLVM folds the tap / K-step offsets into the instructions instead of hoisting one address register per read.
-    auto mfma_tile = [&]() __attribute__((always_inline)) {
-        constexpr int NJ = NKT * TAPS, PF = KS == 3 ? 6 : 2;
+    auto mfma_taps = [&](auto TAP0, auto NTAP) __attribute__((always_inline)) {
+        constexpr int T0 = decltype(TAP0)::value, NTP = decltype(NTAP)::value;   // this wave's taps [T0, T0 + NTP)
+        constexpr int NJ = NKT * NTP, PF = NTP >= 4 ? 6 : 2;
         uint32_t ga[NR], hb[NKT][NR];
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgK k) {
         }
         V16 aq[2], bq[PF];
         auto bfrag = [&](int j) __attribute__((always_inline)) {
-            const int s = j / TAPS, tap = j % TAPS;
+            const int s = j / NTP, tap = T0 + j % NTP;
             uint32_t ad[NR];
 #pragma unroll
             for (int i = 0; i < NR; ++i) ad[i] = hb[s][i] + (tap / KS) * hrow;
@@ -260,10 +265,18 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgK k) {
         for (int j = 0; j < PF - 1 && j < NJ; ++j) bq[j] = bfrag(j);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int s = j / TAPS, tap = j % TAPS;
-            if (tap == 0 && s + 1 < NKT) aq[(s + 1) & 1] = frag_at<T>(ga, (s + 1) * KSTEP * PS);
+            const int s = j / NTP, jt = j % NTP;
+            if (jt == 0 && s + 1 < NKT) aq[(s + 1) & 1] = frag_at<T>(ga, (s + 1) * KSTEP * PS);
             if (j + PF - 1 < NJ) bq[(j + PF - 1) % PF] = bfrag(j + PF - 1);
-            mma16<T>(acc[tap], aq[s & 1], bq[j % PF]);
+            mma16<T>(acc[jt], aq[s & 1], bq[j % PF]);
+        }
+    };
+    auto mfma_tile = [&]() __attribute__((always_inline)) {
+        if constexpr (NTG == 1) {
+            mfma_taps(std::integral_constant<int, 0>{}, std::integral_constant<int, TAPS>{});
+        } else {
+            if (tg == 0) mfma_taps(std::integral_constant<int, 0>{}, std::integral_constant<int, TPG>{});          // wave-uniform
+            else mfma_taps(std::integral_constant<int, TPG>{}, std::integral_constant<int, TAPS - TPG>{});
         }
     };
 
@@ -314,31 +327,32 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgK k) {
         body(I1);
     }
     WSTAMP(6);
-    {   // every wave writes its quadrant of the block's slab [Co][taps][Ci]
+    {   // every wave writes its quadrant (and its taps) of the block's slab [Co][taps][Ci]
         float* slab = p.partial + (size_t)blockIdx.x * p.Co * TAPS * p.Ci;
         const int ci = ci0 + nt * 16 + (lane & 15), co = co0 + mt * 16 + 4 * g;
-        float* dst = slab + (size_t)co * TAPS * p.Ci + ci;
+        const int tap0 = tg * TPG;
+        float* dst = slab + ((size_t)co * TAPS + tap0) * p.Ci + ci;
         if (ci < p.Ci) {
 #pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap)
+            for (int jt = 0; jt < TPG; ++jt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (co + r < p.Co) dst[((size_t)r * TAPS + tap) * p.Ci] = acc[tap][r];
+                    if (tap0 + jt < TAPS && co + r < p.Co) dst[((size_t)r * TAPS + jt) * p.Ci] = acc[jt][r];
         }
     }
     WSTAMP(8);
 }
 
-template <typename T, int KS, int NVH, bool GQ, int TPX = 128>
+template <typename T, int KS, int NVH, bool GQ, int TPX = 128, int NW = 4>
 int launch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
-    constexpr int OCC = (NVH <= 6 && TPX == 128 && sizeof(T) == 2) ? 2 : 1;
+    constexpr int OCC = (NVH * NW <= 24 && TPX == 128 && sizeof(T) == 2) ? 2 : 1;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, KS, NVH, GQ, TPX, OCC>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, KS, NVH, GQ, TPX, OCC, NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((wgrad_kernel<T, KS, NVH, GQ, TPX, OCC>), grid, dim3(256), lds, st, k);
+    hipLaunchKernelGGL((wgrad_kernel<T, KS, NVH, GQ, TPX, OCC, NW>), grid, dim3(64 * NW), lds, st, k);
     STL_LAUNCH_CHECK("conv_wgrad");
     return 0;
 }
@@ -623,6 +637,16 @@ int dispatch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
             if (nvh <= 6) return gq ? launch<T, KS, 6, true, 256>(k, grid, lds, st) : launch<T, KS, 6, false, 256>(k, grid, lds, st);
         }
         return stl_set_error("wgrad: 256-pixel tiles need bf16 and a halo of at most 384 pixels (have %d)", k.HP);
+    }
+    if constexpr (sizeof(T) == 2 && KS == 3) {   // 8 waves: quadrants x two tap groups, half the staging work per thread
+        static const int nw_env = getenv("STL_WGRAD_NW") ? atoi(getenv("STL_WGRAD_NW")) : 8;
+        if (nw_env == 8) {
+            const int nvh8 = ceil_div(k.HP * vpx, 512);
+            if (nvh8 <= 2) return gq ? launch<T, KS, 2, true, 128, 8>(k, grid, lds, st) : launch<T, KS, 2, false, 128, 8>(k, grid, lds, st);
+            if (nvh8 <= 3) return gq ? launch<T, KS, 3, true, 128, 8>(k, grid, lds, st) : launch<T, KS, 3, false, 128, 8>(k, grid, lds, st);
+            if (nvh8 <= 5) return gq ? launch<T, KS, 5, true, 128, 8>(k, grid, lds, st) : launch<T, KS, 5, false, 128, 8>(k, grid, lds, st);
+            if (nvh8 <= 9) return gq ? launch<T, KS, 9, true, 128, 8>(k, grid, lds, st) : launch<T, KS, 9, false, 128, 8>(k, grid, lds, st);
+        }
     }
     if (nvh <= 3) return gq ? launch<T, KS, 3, true>(k, grid, lds, st) : launch<T, KS, 3, false>(k, grid, lds, st);
     if (nvh <= 6) return gq ? launch<T, KS, 6, true>(k, grid, lds, st) : launch<T, KS, 6, false>(k, grid, lds, st);
