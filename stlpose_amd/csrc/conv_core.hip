@@ -98,6 +98,9 @@ __device__ __forceinline__ void store4(void* base, size_t elem, const float* f) 
     }
 }
 
+#ifndef STL_PIN_TAPS
+#define STL_PIN_TAPS 1
+#endif
 #include "conv_common.inc"
 
 // WM x WN waves, MT pixel tiles and NTW channel tiles per wave; NVA staging vectors per thread for
@@ -430,7 +433,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
         }
         issue(a_go, chn * CK, have_n);  // next stage's loads land during the MFMAs below
         if (ch0 == 0) STAMP(6);
-        {  // fragment reads of tap t+1 are issued before the MFMAs of tap t (static double buffer)
+        {  // fragment reads of tap t+1 are issued before the MFMAs of tap t (static double buffer).  PIN: the order is
+           // pinned with scheduling barriers -- left alone, the scheduler sinks every read to just in front of its
+           // first use to save registers, and each MFMA pair then waits a full LDS round trip
+            constexpr bool PIN = (STL_PIN_TAPS != 0) && !FW;
             V16 wf[2][NTW], xf[2][MT];
 #pragma unroll
             for (int ni = 0; ni < NTW; ++ni) wf[0][ni] = *reinterpret_cast<const V16*>(sB + woff + ni * 16 * ROWB);
@@ -446,10 +452,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 #pragma unroll
                     for (int mi = 0; mi < MT; ++mi) xf[(tap + 1) & 1][mi] = *reinterpret_cast<const V16*>(sA + xoff[mi] + toff);
                 }
+                if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NTW; ++ni) mma16<T>(acc[mi][ni], wf[tap & 1][ni], xf[tap & 1][mi]);
+                if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
             }
         }
         if constexpr (FW) {
