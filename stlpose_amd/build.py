@@ -21,15 +21,20 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> str:
+    """stamps=True: a second library, libstlpose_hip_stamps.so, with the in-kernel phase stamps compiled in
+    (-DSTL_STAMPS; tools/conv_stamps.py and tools/wgrad_probe.py load it through STLPOSE_HIP_LIB).  The product
+    library never carries them: see the note at STAMP() in conv_core.hip."""
+    lib = LIB.replace(".so", "_stamps.so") if stamps else LIB
+    suffix, extra = (".stamps.o", ["-DSTL_STAMPS"]) if stamps else (".o", [])
     hdrs = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "conv_common.inc"), os.path.join(CSRC, "conv_ws.inc"), os.path.join(CSRC, "conv1x1.inc"),
             os.path.join(HERE, "..", "include", "stlpose_hip.h")]
     objs, jobs = [], []
     for s in SOURCES:
-        src, obj = os.path.join(CSRC, s), os.path.join(CSRC, s.replace(".hip", ".o"))
+        src, obj = os.path.join(CSRC, s), os.path.join(CSRC, s.replace(".hip", suffix))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
+            jobs.append([HIPCC, *FLAGS, *extra, "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -41,10 +46,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(r.stderr, file=sys.stderr)
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, stamps="--stamps" in sys.argv))

@@ -27,10 +27,17 @@ constexpr int PSA = 96;
 // debug-only phase stamps (block 0, thread 0; enabled by STL_CONV_STAMPS=1): never read by the kernel
 __device__ long long g_stamps[32];
 __device__ long long g_stamps2[64];  // wave-specialised kernel: [0..23] loader, [32..55] compute (6 stages x 4)
+// Compiled in only with -DSTL_STAMPS (python -m stlpose_amd.build --stamps -> libstlpose_hip_stamps.so): even when
+// disabled at run time, the stores make the compiler place s_waitcnt vmcnt() in front of whatever reuses their data
+// registers -- in the stage loop that drains loads which were meant to stay in flight.
+#ifdef STL_STAMPS
 #define STAMP(i)                                                          \
     do {                                                                  \
         if (k.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); \
     } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 
 struct ConvK {
     stl_conv p;
@@ -143,7 +150,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     const bool wres = WR < 0 ? (k.wres != 0) : (WR == 1);
 
     STAMP(0);
+#ifdef STL_STAMPS
     if (k.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[12] = __builtin_amdgcn_s_memtime();
+#endif
     float* cs = reinterpret_cast<float*>(smem + k.off_cs);  // [3][cipad] source transform
     float* cm = reinterpret_cast<float*>(smem + k.off_cm);  // [4][BCO]   mask BN: a, b, mean, rstd
     char* sA = smem + k.off_a;
@@ -415,6 +424,26 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
         }
     };
 
+    // epilogue operands (addend / masks) of all MT tiles of the wave, fetched in one burst: before the MFMAs of the
+    // tile's last chunk where the block owns its CU anyway (EPRE: 12 registers per tile), else at the start of the epilogue
+    constexpr bool EPRE = (OCC <= 1 && WM == 4 && WN == 2 && NTW == 2 && Q && !FW);
+    auto epi_fetch = [&](int vr0, int c0, bool* pokv, size_t* pixv, EpiRaw<NTW>* er) __attribute__((always_inline)) {
+        const int eb0 = fdiv(vr0, k.r_vp), ey0 = vr0 - eb0 * vpitch;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            bool pok = e_yx[mi] >= 0;
+            int oy = ey0 + (e_yx[mi] >> 16), b = eb0;
+            const int c = c0 + (e_yx[mi] & 0xffff);
+            if (pok) {
+                while (oy >= vpitch) oy -= vpitch, ++b;
+                pok = (b < p.B) && (oy < p.Ho) && (c < p.Wo);
+            }
+            pokv[mi] = pok;
+            pixv[mi] = pok ? (((size_t)b * p.Ho + oy) * p.Wo + c) * p.Co : 0;
+            epilogue_fetch<T, NTW, true>(p, pok, pixv[mi], n0, wn * NTW * 16, g, er[mi]);
+        }
+    };
+
     // flat loop over stages (tile, chunk); exactly ONE issue() site inside the loop so that the
     // staging registers need no PHI copies (which would force a vmcnt(0) before the MFMAs)
     while (have) {
@@ -430,6 +459,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
             itn = it + nx, tn = xcd * T8 + itn, chn = 0;
             have_n = (itn < T8) && (tn < k.npt);
             if (have_n) tile_setup(tn, a_go);
+        }
+        bool pokv[EPRE ? MT : 1];
+        size_t pixv[EPRE ? MT : 1];
+        EpiRaw<NTW> er[EPRE ? MT : 1];
+        if constexpr (EPRE) {
+            if (last_chunk) epi_fetch(vr0, c0, pokv, pixv, er);   // ahead of the next stage's loads: consumed behind a counted wait
         }
         issue(a_go, chn * CK, have_n);  // next stage's loads land during the MFMAs below
         if (ch0 == 0) STAMP(6);
@@ -470,18 +505,24 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
         if (last_chunk) {
             STAMP(8);
             // ---- epilogue straight from the accumulators: lane = pixel r16, 4 channels per tile
-            const int eb0 = fdiv(vr0, k.r_vp), ey0 = vr0 - eb0 * vpitch;
+            if constexpr (EPRE) {
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
-                bool pok = e_yx[mi] >= 0;
-                int oy = ey0 + (e_yx[mi] >> 16), b = eb0;
-                const int c = c0 + (e_yx[mi] & 0xffff);
-                if (pok) {
-                    while (oy >= vpitch) oy -= vpitch, ++b;
-                    pok = (b < p.B) && (oy < p.Ho) && (c < p.Wo);
+                for (int mi = 0; mi < MT; ++mi)
+                    epilogue_apply<T, NTW, BCO>(p, acc[mi], cm, pokv[mi], pixv[mi], n0, wn * NTW * 16, g, s0, s1, er[mi]);
+            } else {   // register-tight instantiations: tile by tile
+                const int eb0 = fdiv(vr0, k.r_vp), ey0 = vr0 - eb0 * vpitch;
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    bool pok = e_yx[mi] >= 0;
+                    int oy = ey0 + (e_yx[mi] >> 16), b = eb0;
+                    const int c = c0 + (e_yx[mi] & 0xffff);
+                    if (pok) {
+                        while (oy >= vpitch) oy -= vpitch, ++b;
+                        pok = (b < p.B) && (oy < p.Ho) && (c < p.Wo);
+                    }
+                    const size_t pix = pok ? (((size_t)b * p.Ho + oy) * p.Wo + c) * p.Co : 0;
+                    epilogue_tile<T, NTW, BCO>(p, acc[mi], cm, pok, pix, n0, wn * NTW * 16, g, s0, s1);
                 }
-                const size_t pix = pok ? (((size_t)b * p.Ho + oy) * p.Wo + c) * p.Co : 0;
-                epilogue_tile<T, NTW, BCO>(p, acc[mi], cm, pok, pix, n0, wn * NTW * 16, g, s0, s1);
             }
         }
         if (last_chunk) STAMP(9);
@@ -535,7 +576,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
         }
     }
     STAMP(11);
+#ifdef STL_STAMPS
     if (k.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[13] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 #include "conv_ws.inc"

@@ -17,10 +17,14 @@ namespace {
 
 // debug-only phase stamps (block 0, thread 0; STL_CONV_STAMPS=1): never read by the kernel
 __device__ long long g_wstamps[16];
+#ifdef STL_STAMPS
 #define WSTAMP(i)                                                                                   \
     do {                                                                                            \
         if (k.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_wstamps[i] = wall_clock64(); \
     } while (0)
+#else
+#define WSTAMP(i) do {} while (0)
+#endif
 
 struct WgK {
     stl_wgrad p;

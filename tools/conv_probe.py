@@ -28,6 +28,29 @@ def run(B, H, W, Ci, Co, ks, s, mode="bn", reps=30, tile=None):
         p.src.stats, p.src.gamma, p.src.beta = sx.data_ptr(), ga.data_ptr(), be.data_ptr()
         p.src.inv_count, p.src.eps = 1.0 / (B * H * W), 1e-5
     p.w, p.out, p.out_stats = w.data_ptr(), out.data_ptr(), st.data_ptr()
+    keep = []
+    if mode in ("dgradA", "dgradB"):   # data gradient of a two-conv unit: BNBWD source, mask (+ addend, block-end mask) epilogue
+        yq = torch.randn(B, H, W, Ci, device="cuda").to(td)
+        rst = torch.zeros(capi.NSHARD * 2 * Ci, dtype=torch.float64, device="cuda")
+        p.src.mode, p.src.relu = capi.SRC_BNBWD, 0
+        p.src.y, p.src.stats, p.src.rstats, p.src.gamma = yq.data_ptr(), sx.data_ptr(), rst.data_ptr(), ga.data_ptr()
+        p.src.inv_count, p.src.eps = 1.0 / (B * H * W), 1e-5
+        my = torch.randn(B, Ho, Wo, Co, device="cuda").to(td)
+        so = torch.zeros(capi.NSHARD, 2, Co, dtype=torch.float64, device="cuda"); so[0, 1] = B * Ho * Wo
+        go, bo = torch.ones(Co, device="cuda"), torch.zeros(Co, device="cuda")
+        red = torch.zeros(capi.NSHARD * 2 * Co, dtype=torch.float64, device="cuda")
+        p.out_stats = None
+        p.mask_y = my.data_ptr()
+        p.mask_bn.x, p.mask_bn.mode, p.mask_bn.relu = my.data_ptr(), capi.SRC_BN, int(mode == "dgradA")
+        p.mask_bn.stats, p.mask_bn.gamma, p.mask_bn.beta = so.data_ptr(), go.data_ptr(), bo.data_ptr()
+        p.mask_bn.inv_count, p.mask_bn.eps = 1.0 / (B * Ho * Wo), 1e-5
+        p.red = red.data_ptr()
+        keep += [yq, rst, my, so, go, bo, red]
+        if mode == "dgradB":
+            ad = torch.randn(B, Ho, Wo, Co, device="cuda").to(td)
+            mz = torch.randn(B, Ho, Wo, Co, device="cuda").to(td)
+            p.addend, p.mask_z = ad.data_ptr(), mz.data_ptr()
+            keep += [ad, mz]
     capi.call("stl_conv_plan", C.byref(p))
     capi.call("stl_conv_plan", C.byref(p))
     stream = torch.cuda.current_stream().cuda_stream
@@ -42,7 +65,7 @@ def run(B, H, W, Ci, Co, ks, s, mode="bn", reps=30, tile=None):
     us = e0.elapsed_time(e1) / reps * 1e3
     fl = 2.0 * B * Ho * Wo * Co * Ci * ks * ks
     by = B * H * W * Ci * 2 + B * Ho * Wo * Co * 2
-    print(f"B{B} {H}x{W} {Ci}->{Co} k{ks}s{s} tile={p.TH}x{p.TW} cap={os.environ.get('STL_CONV_GRID_CAP','-')}: {us:8.1f} us  {fl/us/1e6:7.1f} TF/s  {by/us/1e3:7.1f} GB/s", flush=True)
+    print(f"{mode:6s} B{B} {H}x{W} {Ci}->{Co} k{ks}s{s} tile={p.TH}x{p.TW} cap={os.environ.get('STL_CONV_GRID_CAP','-')}: {us:8.1f} us  {fl/us/1e6:7.1f} TF/s  {by/us/1e3:7.1f} GB/s", flush=True)
 
 if __name__ == "__main__":
     shapes = [(32, 96, 72, 32, 32, 3, 1), (32, 48, 36, 64, 64, 3, 1), (32, 24, 18, 128, 128, 3, 1), (32, 12, 9, 256, 256, 3, 1),

@@ -1,5 +1,8 @@
 import os, sys
 os.environ["STL_CONV_STAMPS"] = "1"
+_st = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "stlpose_amd", "libstlpose_hip_stamps.so")
+assert os.path.exists(_st), "build the stamped library first: python -m stlpose_amd.build --stamps"
+os.environ.setdefault("STLPOSE_HIP_LIB", _st)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C, torch
 from stlpose_amd import capi
@@ -9,7 +12,7 @@ shapes = [(32, 96, 72, 32, 32, 3, 1), (32, 48, 36, 64, 64, 3, 1)]
 if os.environ.get("SHAPES"):
     shapes = [tuple(int(v) for v in t.split(",")) for t in os.environ["SHAPES"].split(";")]
 for shape in shapes:
-    run(*shape, reps=int(os.environ.get('REPS','2')))
+    run(*shape, mode=os.environ.get('MODE', 'bn'), reps=int(os.environ.get('REPS','2')))
     torch.cuda.synchronize()
     buf = (C.c_longlong * 14)()
     capi.call("stl_debug_conv_stamps", C.cast(buf, C.c_void_p))

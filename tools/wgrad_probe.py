@@ -1,5 +1,8 @@
 """Weight-gradient kernel timing vs split factor: separates per-tile from fixed per-launch cost."""
 import os, sys, math, ctypes as C
+_st = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "stlpose_amd", "libstlpose_hip_stamps.so")
+if os.environ.get("STL_CONV_STAMPS") and os.path.exists(_st):   # stamps exist only in the -DSTL_STAMPS build
+    os.environ.setdefault("STLPOSE_HIP_LIB", _st)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from stlpose_amd import capi
