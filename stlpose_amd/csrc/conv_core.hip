@@ -426,7 +426,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 
     // epilogue operands (addend / masks) of all MT tiles of the wave, fetched in one burst: before the MFMAs of the
     // tile's last chunk where the block owns its CU anyway (EPRE: 12 registers per tile), else at the start of the epilogue
-    constexpr bool EPRE = (OCC <= 1 && WM == 4 && WN == 2 && NTW == 2 && Q && !FW);
+    constexpr bool EPRE = (OCC <= 1 && WM == 4 && WN == 2 && NTW == 2 && Q && !FW && sizeof(T) == 2);   // fp32 would need 96 registers and spills
     auto epi_fetch = [&](int vr0, int c0, bool* pokv, size_t* pixv, EpiRaw<NTW>* er) __attribute__((always_inline)) {
         const int eb0 = fdiv(vr0, k.r_vp), ey0 = vr0 - eb0 * vpitch;
 #pragma unroll

@@ -642,7 +642,7 @@ int dispatch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
         }
         return stl_set_error("wgrad: 256-pixel tiles need bf16 and a halo of at most 384 pixels (have %d)", k.HP);
     }
-    if constexpr (sizeof(T) == 2 && KS == 3) {   // 8 waves: quadrants x two tap groups, half the staging work per thread
+    if constexpr (KS == 3) {   // 8 waves: quadrants x two tap groups, half the staging work per thread (bf16 and fp32)
         static const int nw_env = getenv("STL_WGRAD_NW") ? atoi(getenv("STL_WGRAD_NW")) : 8;
         if (nw_env == 8) {
             const int nvh8 = ceil_div(k.HP * vpx, 512);

@@ -10,17 +10,19 @@ from stlpose_amd.engine import choose_tile
 
 def run(B, H, W, Ci, Co, ks, maxpx, splits, gq=True):
     dev = "cuda"
-    x = torch.randn(B * H * W * Ci, device=dev).bfloat16()
-    dt = torch.randn(B * H * W * Co, device=dev).bfloat16()
-    y = torch.randn(B * H * W * Co, device=dev).bfloat16()
+    f32 = os.environ.get("DTYPE", "bf16") == "fp32"
+    td = torch.float32 if f32 else torch.bfloat16
+    x = torch.randn(B * H * W * Ci, device=dev).to(td)
+    dt = torch.randn(B * H * W * Co, device=dev).to(td)
+    y = torch.randn(B * H * W * Co, device=dev).to(td)
     st = torch.zeros(capi.NSHARD * 2 * Co, dtype=torch.float64, device=dev); st[Co:2 * Co] = B * H * W
     st1 = torch.zeros(capi.NSHARD * 2 * Ci, dtype=torch.float64, device=dev); st1[Ci:2 * Ci] = B * H * W
     rst = torch.zeros(capi.NSHARD * 2 * Co, dtype=torch.float64, device=dev)
     ga = torch.ones(max(Ci, Co), device=dev); be = torch.zeros(max(Ci, Co), device=dev)
     wg = capi.Wgrad()
-    wg.dtype, wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = 1, B, H, W, Ci, H, W, Co
+    wg.dtype, wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = (0 if f32 else 1), B, H, W, Ci, H, W, Co
     wg.ks, wg.stride = ks, 1
-    wg.TH, wg.TW = choose_tile(B, H, W, 1, ks, 2, bn_cols=32, maxpx=maxpx, maxhalo=384 if maxpx == 256 else 576)
+    wg.TH, wg.TW = choose_tile(B, H, W, 1, ks, 4 if f32 else 2, bn_cols=32, maxpx=maxpx, maxhalo=384 if maxpx == 256 else 576)
     npt = math.ceil(B * (H + 1) / wg.TH) * math.ceil(W / wg.TW)
     wg.h.x, wg.h.mode, wg.h.relu = x.data_ptr(), capi.SRC_BN, 1
     wg.h.stats, wg.h.gamma, wg.h.beta, wg.h.inv_count, wg.h.eps = st1.data_ptr(), ga.data_ptr(), be.data_ptr(), 1.0 / (B * H * W), 1e-5
