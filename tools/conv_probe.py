@@ -7,10 +7,17 @@ from stlpose_amd.engine import choose_tile
 
 def run(B, H, W, Ci, Co, ks, s, mode="bn", reps=30, tile=None):
     td = torch.bfloat16
-    x = torch.randn(B, H, W, Ci, device="cuda").to(td)
+    stuff = mode.startswith("s2")     # s2dA / s2dB: data gradient of a stride-2 conv, H x W is its OUTPUT (the forward conv's input)
+    if stuff:
+        mode = "dgrad" + mode[3:]
+        Hs, Ws = (H + 1) // 2, (W + 1) // 2
+    x = torch.randn(B, (Hs if stuff else H), (Ws if stuff else W), Ci, device="cuda").to(td)
     w = (torch.randn(Co, ks * ks, Ci, device="cuda") / math.sqrt(Ci * ks * ks)).to(td)
     pad = 1 if ks == 3 else 0
     Ho, Wo = (H + 2 * pad - ks) // s + 1, (W + 2 * pad - ks) // s + 1
+    if stuff:
+        Ho, Wo = H, W
+        H, W = Hs, Ws
     out = torch.empty(B, Ho, Wo, Co, device="cuda", dtype=td)
     st = torch.zeros(capi.NSHARD * 2 * Co, dtype=torch.float64, device="cuda")
     sx = torch.zeros(capi.NSHARD, 2, Ci, dtype=torch.float64, device="cuda")
@@ -21,6 +28,7 @@ def run(B, H, W, Ci, Co, ks, s, mode="bn", reps=30, tile=None):
     p.shape = -1
     p.dtype, p.B, p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.Co = capi.BF16, B, H, W, Ci, Ho, Wo, Co
     p.ks, p.stride = ks, s
+    p.stuff = int(stuff)
     p.TH, p.TW = tile or (0, 0)
     p.src.x = x.data_ptr()
     if mode == "bn":
