@@ -291,20 +291,35 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const void* x, const floa
     }
 }
 
+// dx = dout . w per pixel (17 FMAs per element, VALU), and the weight / bias gradient of the block's pixels:
+// dw[j][c] = sum_px d[px][j] * x[px][c] is a [J x 256] . [256 x Ci] product per 256-pixel chunk -- on the fp32 matrix
+// cores (v_mfma_f32_16x16x4_f32, operands straight out of the LDS copies the chunk needs anyway: each wave a quarter
+// of the pixels, accumulators kept across the block's chunks, one cross-wave reduction at the end).  The scalar LDS
+// loop this replaces (561 outputs x 256 pixels x 2 reads per chunk) made the head the slowest launch per byte of the
+// step: 78 us at the very start of backward, where nothing else can run.
 template <typename T, int J>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const void* x, const float* w, const float* dout, void* dx,
                                                        float* partial, int B, int HW, int Ci) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SDP = 260;                     // row pitch of sd in floats: 16-byte aligned rows, conflict-free 16-row column reads
+    constexpr int NTMAX = 4;                     // Ci <= 64
     float* sw = reinterpret_cast<float*>(smem);  // [J][Ci]
-    float* sd = sw + J * Ci;                     // [J][256]
-    float* sx = sd + J * 256;                    // [256][Ci+1]
-    for (int e = threadIdx.x; e < J * Ci; e += 256) sw[e] = w[e];
+    float* sd = sw + ((J * Ci + 3) & ~3);        // [J][SDP]
+    float* sx = sd + J * SDP;                    // [256][Ci+1]; reused for the cross-wave reduction at the end
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+    const int nt_n = Ci >> 4;
+    for (int e = tid; e < J * Ci; e += 256) sw[e] = w[e];
     const int nel = J * Ci + J;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // up to 4 dw/db elements per thread (nel <= 1024)
+    f32x4 acc[2][NTMAX];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTMAX; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;                            // thread (j = tid >> 2, quarter = tid & 3): bias gradient partial
     const size_t P = (size_t)B * HW;
     const size_t nchunk = (P + 255) / 256;
     for (size_t ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
-        const size_t pi = ch * 256 + threadIdx.x;
+        const size_t pi = ch * 256 + tid;
         __syncthreads();
         float d[J];
         if (pi < P) {
@@ -316,7 +331,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const void* x, const floa
             for (int j = 0; j < J; ++j) d[j] = 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < J; ++j) sd[j * 256 + threadIdx.x] = d[j];
+        for (int j = 0; j < J; ++j) sd[j * SDP + tid] = d[j];
         for (int c0 = 0; c0 < Ci; c0 += 8) {
             float f[8], gx[8];
             if (pi < P) {
@@ -327,7 +342,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const void* x, const floa
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                sx[threadIdx.x * (Ci + 1) + c0 + q] = f[q];
+                sx[tid * (Ci + 1) + c0 + q] = f[q];
                 float s = 0.f;
 #pragma unroll
                 for (int j = 0; j < J; ++j) s = fmaf(d[j], sw[j * Ci + c0 + q], s);
@@ -336,23 +351,61 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const void* x, const floa
             if (pi < P) store8<T>(dx, pi * Ci + c0, gx);
         }
         __syncthreads();
-        for (int r = 0; r < 4; ++r) {
-            const int e = threadIdx.x + r * 256;
-            if (e >= nel) break;
-            float s = 0.f;
-            if (e < J * Ci) {
-                const int j = e / Ci, c = e - j * Ci;
-                for (int q = 0; q < 256; ++q) s = fmaf(sd[j * 256 + q], sx[q * (Ci + 1) + c], s);
-            } else {
-                const int j = e - J * Ci;
-                for (int q = 0; q < 256; ++q) s += sd[j * 256 + q];
+        // ---- dw += d^T . x over this wave's 64 pixels: A[i = j][k = pixel] from sd, B[k = pixel][n = c] from sx
+        const int px0 = wave * 64 + g;
+        const float* arow0 = sd + r16 * SDP + px0;                      // j = r16       (always < J)
+        const float* arow1 = sd + (16 + r16 < J ? 16 + r16 : 0) * SDP + px0;   // j = 16 + r16  (zeroed when >= J)
+        const bool a1ok = 16 + r16 < J;
+        const float* brow = sx + (size_t)px0 * (Ci + 1) + r16;
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+            const float a0 = arow0[4 * ks];
+            const float a1 = a1ok ? arow1[4 * ks] : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NTMAX; ++nt) {
+                if (nt < nt_n) {
+                    const float bv = brow[(size_t)4 * ks * (Ci + 1) + nt * 16];
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[1][nt], 0, 0, 0);
+                }
             }
-            if (r == 0) a0 += s; else if (r == 1) a1 += s; else if (r == 2) a2 += s; else a3 += s;
+        }
+        // ---- db: 4 threads per joint, 64 pixels each
+        if (tid < 4 * J) {
+            const float* r = sd + (tid >> 2) * SDP + (tid & 3) * 64;
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(r + 4 * q);
+                s += (v.x + v.y) + (v.z + v.w);
+            }
+            bsum += s;
         }
     }
-    for (int r = 0; r < 4; ++r) {
-        const int e = threadIdx.x + r * 256;
-        if (e < nel) partial[(size_t)blockIdx.x * nel + e] = r == 0 ? a0 : r == 1 ? a1 : r == 2 ? a2 : a3;
+    // ---- cross-wave reduction through LDS (fixed order: deterministic), one slab per block
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(sx);   // [wave][mt * NTMAX + nt][lane]
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTMAX; ++nt)
+            if (nt < nt_n) red[(wave * 2 * NTMAX + mt * NTMAX + nt) * 64 + lane] = acc[mt][nt];
+    float* bred = reinterpret_cast<float*>(red + 4 * 2 * NTMAX * 64);   // [4 J]
+    if (tid < 4 * J) bred[tid] = bsum;
+    __syncthreads();
+    for (int e = tid; e < nel; e += 256) {
+        float s;
+        if (e < J * Ci) {
+            // D[i][n]: lane = 16 * (i / 4) + n, register i % 4;  i = j % 16, n = c % 16
+            const int j = e / Ci, c = e - j * Ci;
+            const int tile = (j >> 4) * NTMAX + (c >> 4), ln = 16 * ((j & 15) >> 2) + (c & 15), rr = j & 3;
+            s = (red[(0 * 2 * NTMAX + tile) * 64 + ln][rr] + red[(1 * 2 * NTMAX + tile) * 64 + ln][rr]) +
+                (red[(2 * 2 * NTMAX + tile) * 64 + ln][rr] + red[(3 * 2 * NTMAX + tile) * 64 + ln][rr]);
+        } else {
+            const int j = e - J * Ci;
+            s = (bred[4 * j] + bred[4 * j + 1]) + (bred[4 * j + 2] + bred[4 * j + 3]);
+        }
+        partial[(size_t)blockIdx.x * nel + e] = s;
     }
 }
 
@@ -976,7 +1029,10 @@ extern "C" int stl_head_backward(int dtype, const void* x, const float* w, const
     STL_CHECK(J == 17 || J == 16, "head_bwd: J=%d unsupported", J);
     STL_CHECK(Ci % 8 == 0 && J * Ci + J <= 1024, "head_bwd: Ci=%d", Ci);
     STL_CHECK(nblk >= 1, "head_bwd: nblk");
-    const size_t lds = (size_t)(J * Ci + J * 256 + 256 * (Ci + 1)) * 4;
+    STL_CHECK(Ci % 16 == 0 && Ci <= 64, "head_bwd: Ci=%d must be a multiple of 16, at most 64", Ci);
+    size_t lds = (size_t)(((J * Ci + 3) & ~3) + J * 260 + 256 * (Ci + 1)) * 4;
+    const size_t lds_red = (size_t)(((J * Ci + 3) & ~3) + J * 260) * 4 + (size_t)4 * 2 * 4 * 64 * 16 + 4 * J * 4;   // reduction buffers alias sx
+    if (lds_red > lds) lds = lds_red;
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<__bf16, 17>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

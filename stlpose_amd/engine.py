@@ -404,7 +404,7 @@ class Engine:
             if kind == "head":
                 _, x, key, joints = node
                 x.bwd_seen += 1
-                nblk = 256
+                nblk = max(1, min(int(os.environ.get("STLPOSE_HEAD_BLOCKS", "256")), math.ceil(x.B * x.H * x.W / 256)))   # <= one 256-pixel chunk per block
                 dx = self._new_grad(x)
                 nel = joints * x.C + joints
                 part_off = self._slab_elems
