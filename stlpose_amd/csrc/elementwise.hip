@@ -552,31 +552,46 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* master, T
     const int t = e.ks * e.ks;
     const int64_t tot = (int64_t)e.Co * e.Ci * t;
     const int64_t base = (int64_t)(bx - e.blk0) * 1024;
-    if (!e.patch && (e.Ci & 3) == 0 && (e.Co & 3) == 0) {
-        // Output-major: every thread produces 4 CONSECUTIVE elements of each kernel layout (8 / 16-byte stores,
-        // a wave writes whole lines) and gathers its 4 sources from the OIHW master (strided 4-byte reads that
-        // the caches absorb).  The input-major form below stores single 2-byte elements at stride Ci resp. Co:
-        // 1.3 GB of partial-line writes per step for 114 MB of weights (0.31 ms; profiles/r01_step_traffic.txt).
-        const int64_t o = base + 4 * threadIdx.x;
-        if (o >= tot) return;
-        T v[4];
-        {   // forward layout [co][tap][ci]
-            const int ci = (int)(o % e.Ci);
-            const int64_t r = o / e.Ci;
-            const int tap = (int)(r % t), co = (int)(r / t);
-            const float* src = master + e.src_off + ((int64_t)co * e.Ci + ci) * t + tap;
+    if (!e.patch && (e.Ci & 3) == 0 && (e.Co & 3) == 0 && t <= 9) {
+        // 32 x 32 channel tiles through LDS: the OIHW master is read ONCE in contiguous (32 ci x taps) row segments,
+        // both kernel layouts are written in 4-element vectors that form 64-byte runs ([co][tap][ci0..ci0+32) and
+        // [ci][flipped tap][co0..co0+32)).  The table still counts 1024-element blocks per conv; the blocks of a conv
+        // share its tiles round robin.  (Output-major gathers -- 4-byte reads at stride taps resp. Ci*taps -- moved
+        // 8x the bytes of the master: 158 us at the head of every step.)
+        __shared__ float st[32 * (32 * 9 + 1)];
+        const int pitch = 32 * t + 1;
+        const int tci = (e.Ci + 31) >> 5, ntiles = ((e.Co + 31) >> 5) * tci;
+        const int nblk = (int)((tot + 1023) / 1024);
+        const float* src0 = master + e.src_off;
+        for (int tile = bx - e.blk0; tile < ntiles; tile += nblk) {
+            const int co0 = (tile / tci) * 32, ci0 = (tile % tci) * 32;
+            const int nco = min(32, e.Co - co0), nci = min(32, e.Ci - ci0), seg = nci * t;
+            __syncthreads();
+            for (int r = threadIdx.x >> 6; r < nco; r += 4) {   // one wave per co row: contiguous, division-free
+                const float* row = src0 + ((int64_t)(co0 + r) * e.Ci + ci0) * t;
+                for (int c = threadIdx.x & 63; c < seg; c += 64) st[r * pitch + c] = row[c];
+            }
+            __syncthreads();
+            T v[4];
+            // forward layout [co][tap][ci]: task = (row = co_l * t + tap, 4 ci); taps are 1 or 9 (constant divisors)
+            const int q4 = nci >> 2;
+            for (int i = threadIdx.x; i < nco * t * q4; i += 256) {
+                const int row = q4 == 8 ? i >> 3 : i / q4, c4 = (i - row * q4) * 4;
+                const int r = t == 9 ? row / 9 : (t == 1 ? row : row / t), tap = row - r * t;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (T)src[(int64_t)j * t];
-            store_vec4(wk + e.fwd_off + o, v);
-        }
-        if (e.bwd_off >= 0) {   // data-gradient layout [ci][flipped tap][co]
-            const int co = (int)(o % e.Co);
-            const int64_t r = o / e.Co;
-            const int tapf = (int)(r % t), ci = (int)(r / t);
-            const float* src = master + e.src_off + ((int64_t)co * e.Ci + ci) * t + (t - 1 - tapf);
+                for (int j = 0; j < 4; ++j) v[j] = (T)st[r * pitch + (c4 + j) * t + tap];
+                store_vec4(wk + e.fwd_off + ((int64_t)(co0 + r) * t + tap) * e.Ci + ci0 + c4, v);
+            }
+            if (e.bwd_off >= 0) {   // data-gradient layout [ci][flipped tap][co]: task = (row = ci_l * t + tapf, 4 co)
+                const int p4 = nco >> 2;
+                for (int i = threadIdx.x; i < nci * t * p4; i += 256) {
+                    const int row = p4 == 8 ? i >> 3 : i / p4, r4 = (i - row * p4) * 4;
+                    const int c = t == 9 ? row / 9 : (t == 1 ? row : row / t), tapf = row - c * t;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (T)src[(int64_t)j * e.Ci * t];
-            store_vec4(wk + e.bwd_off + o, v);
+                    for (int j = 0; j < 4; ++j) v[j] = (T)st[(r4 + j) * pitch + c * t + (t - 1 - tapf)];
+                    store_vec4(wk + e.bwd_off + ((int64_t)(ci0 + c) * t + tapf) * e.Co + co0 + r4, v);
+                }
+            }
         }
         return;
     }
