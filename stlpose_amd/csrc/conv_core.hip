@@ -713,9 +713,13 @@ Plan choose_plan(const stl_conv& p, int ck) {
         if (shape == 3) continue;  // 256x128 block spills registers; reachable via STL_CONV_SHAPE only
         // 128 px x 32 co blocks (four per CU) win in isolation for the C<=32 3x3 layers (21.7 vs 28.2 us)
         const int s4_maxco = getenv("STL_CONV_SHAPE4_MAXCO") ? atoi(getenv("STL_CONV_SHAPE4_MAXCO")) : 32;
-        const bool c32 = p.wg_partial || (!getenv("STL_CONV_NO_C32_SHAPE4") && p.Co <= s4_maxco && p.stride == 1 && p.ks == 3);
+        // ... except with many input channels on a large map (transition1: 256 -> 32 at 96x72, 8 chunks of K per tile): the
+        // 512 px x 32 co block (8 waves) stages each filter chunk once per 512 pixels instead of once per 128 (105.8 -> 71.8 us)
+        const bool wide_k = p.Co <= 32 && p.Ci >= 128 && p.stride == 1 && p.ks == 3 && !p.stuff && !p.wg_partial && (int64_t)p.B * p.Ho * p.Wo >= 65536;
+        const bool c32 = p.wg_partial || (!getenv("STL_CONV_NO_C32_SHAPE4") && p.Co <= s4_maxco && p.stride == 1 && p.ks == 3 && !wide_k);
         if (shape == 4 && !c32) continue;
         if (c32 && shape != 4) continue;
+        if (wide_k && shape != 1) continue;
         // kernel family: measured on MI355X (tools/conv_probe6.py; end to end the threshold Co >= 256 is the better one) the wave-specialised kernel wins for
         // stride-2 convs and for the small, deep maps (Co >= 256), the uniform kernel elsewhere
         const int ws_minco = getenv("STL_CONV_WS_MINCO") ? atoi(getenv("STL_CONV_WS_MINCO")) : 256;
