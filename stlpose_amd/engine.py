@@ -609,7 +609,10 @@ class Engine:
         profiles/r02_trace_default_summary.txt; on its own branch stream a weight gradient delays the
         data-gradient chain.)  Where the network has fewer branches than streams -- stage 3, stage 2, and the
         single-branch tail (layer1, stem), 40 % of backward -- the idle queues take the off-chain work: each such
-        launch goes to the least-loaded stream among the idle ones and its own, by accumulated estimated time."""
+        launch goes to the least-loaded stream among the idle ones and its own, by accumulated estimated time.
+        In the tail only ONE idle queue is used: its launches stream 113 MB tensors at 3-4 TB/s each, and three
+        weight gradients beside the data-gradient chain slow every one of them down by more than the overlap
+        buys (tail queues 3 / 2 / 1 / 0: 16.98 / 16.86 / 16.82 / 17.33 ms per step)."""
         acc = [0.0] * self.nstreams
         out = []
         for op in ops:
@@ -620,6 +623,12 @@ class Engine:
                 own = strm % self.nstreams
                 if os.environ.get("STLPOSE_BALANCE", "idle") == "idle":
                     cands = list(range(active, self.nstreams)) + [own]
+                    nq = int(os.environ.get("STLPOSE_OFFCHAIN_QUEUES", "0"))   # 0 = every idle queue
+                    tq = int(os.environ.get("STLPOSE_TAIL_QUEUES", "1"))       # same, for the single-branch tail only (0 = all three)
+                    if active == 1 and tq:
+                        cands = list(range(1, min(1 + tq, self.nstreams))) + [own]
+                    elif nq:
+                        cands = list(range(active, min(active + nq, self.nstreams))) + [own]
                 else:   # any stream: a foreign weight gradient is issued behind that branch's ops of the module and
                     cands = range(self.nstreams)   # only waits for a data gradient the next exchange needs anyway
                 strm = min(cands, key=lambda s_: (acc[s_], s_ != own))
