@@ -877,7 +877,7 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     // The budget is for the whole grid (pixel blocks x channel blocks): one resident round of blocks
     // (256 for the 8-wave shapes, 1024 for the 4-wave ones); with ny channel blocks per pixel tile the
     // pixel dimension gets budget / ny (3x3 32->256 at 96x72: 102 -> 90 us; tools/conv_probe8.py)
-    static const int cap4 = getenv("STL_CONV_GRID_CAP4") ? atoi(getenv("STL_CONV_GRID_CAP4")) : 1024;
+    static const int cap4 = getenv("STL_CONV_GRID_CAP4") ? atoi(getenv("STL_CONV_GRID_CAP4")) : 768;   // 1024 -> 768: 16.62 -> 16.56 ms/step (three resident blocks per CU leave room for the co-running kernels)
     static const int cap8 = getenv("STL_CONV_GRID_CAP8") ? atoi(getenv("STL_CONV_GRID_CAP8")) : 256;
     int cap = sh.ws ? 256 : (sh.thr == 512 ? cap8 : cap4);
     if (!getenv("STL_CONV_CAP_PER_TILE")) cap = std::max(8, (cap / k.ny + 7) / 8 * 8);

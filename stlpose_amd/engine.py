@@ -356,7 +356,7 @@ class Engine:
         # layers first).  Each bucket gets one ranged slab reduction + BN-gradient launch inside the
         # program, so the step has no serial tail, and an event a data-parallel all-reduce can wait on.
         self.buckets: List[dict] = []
-        bucket_min = int(float(os.environ.get("STLPOSE_BUCKET_MB", "16")) * (1 << 20) / 4)
+        bucket_min = int(float(os.environ.get("STLPOSE_BUCKET_MB", "32")) * (1 << 20) / 4)   # 16 -> 32 MB: 16.79 -> 16.66 ms/step (fewer, larger reductions and collectives)
         bk = dict(done=0, lo=st.nparam, hi=st.nparam, slab0=0, reads=[], strm=0)
         # The serial tail of backward (layer1 + stem: one branch, 113 MB tensors) finishes last.  Close a bucket
         # where it begins, whatever its size, so that the final slab reduction (the only work left after the last
@@ -694,9 +694,9 @@ class Engine:
                                        maxhalo=192 if ctile == 64 else 576)
         npt = math.ceil(x.B * (y.H + 1) / wg.TH) * math.ceil(y.W / wg.TW)
         chunks = math.ceil(y.C / ctile) * math.ceil(x.C / ctile)
-        # Block budget per launch: one block per CU.  (End to end, budgets of 128..256 measure the
-        # same within run-to-run noise on MI355X: fewer blocks mean fewer slab bytes but a longer
-        # launch; 256 keeps the launch itself fastest.)
+        # Block budget per launch: one block per CU.  (End to end, budgets of 128..256 measure the same within
+        # run-to-run noise on MI355X, before and after the kernel was rebuilt: fewer blocks mean fewer slab bytes
+        # but a longer launch; 96 and 384 are clearly worse.)
         budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS", "256"))
         if ctile == 64:
             budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS64", "512"))
