@@ -616,10 +616,11 @@ struct Shape {
     int lthr, nva_max; // threads that stage the halo, max staging vectors per such thread
 };
 // 0..4: uniform-wave kernel (conv_core_kernel); 5..7: wave-specialised kernel (conv_ws_kernel)
-constexpr int NSHAPES = 8;
+constexpr int NSHAPES = 9;   // 8 = 256 px x 32 co (8 waves: two 128-pixel halves share one filter copy and one halo tile)
 constexpr Shape SHAPES[NSHAPES] = {{128, 64, 256, 0, 256, 9}, {512, 32, 512, 0, 512, 6}, {256, 64, 512, 0, 512, 3},
                                    {256, 128, 512, 0, 512, 3}, {128, 32, 256, 0, 256, 6},
-                                   {512, 32, 512, 1, 256, 10}, {256, 64, 512, 1, 256, 6}, {128, 64, 512, 1, 256, 9}};
+                                   {512, 32, 512, 1, 256, 10}, {256, 64, 512, 1, 256, 6}, {128, 64, 512, 1, 256, 9},
+                                   {256, 32, 512, 0, 512, 3}};
 
 template <typename T, int KS, bool Q>
 int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
@@ -636,6 +637,10 @@ int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStrea
             break;
         case 3:
             if (nva <= 3) return launch<T, KS, 4, 2, 4, 4, 3, Q>(k, grid, lds, st);
+            break;
+        case 8:
+            if (nva <= 3 && k.wres) return launch<T, KS, 8, 1, 2, 2, 3, Q, 4, 1>(k, grid, lds, st);
+            if (nva <= 3) return launch<T, KS, 8, 1, 2, 2, 3, Q, (Q ? 3 : 4)>(k, grid, lds, st);
             break;
         case 4:
             if (nva <= 3 && k.wres) return launch<T, KS, 4, 1, 2, 2, 3, Q, 4, 1>(k, grid, lds, st);  // 113-123 VGPRs, no spills
@@ -709,7 +714,7 @@ Plan choose_plan(const stl_conv& p, int ck) {
     for (int shape = 0; shape < NSHAPES; ++shape) {
         const Shape sh = SHAPES[shape];
         if (sh.px > 128 && p.stride == 2) continue;  // stride-2 halos only fit the small blocks
-        if ((shape == 1 || shape == 5) && p.Co > 32) continue;
+        if ((shape == 1 || shape == 5 || shape == 8) && p.Co > 32) continue;
         if (shape == 3) continue;  // 256x128 block spills registers; reachable via STL_CONV_SHAPE only
         // 128 px x 32 co blocks (four per CU) win in isolation for the C<=32 3x3 layers (21.7 vs 28.2 us)
         const int s4_maxco = getenv("STL_CONV_SHAPE4_MAXCO") ? atoi(getenv("STL_CONV_SHAPE4_MAXCO")) : 32;
@@ -717,8 +722,14 @@ Plan choose_plan(const stl_conv& p, int ck) {
         // 512 px x 32 co block (8 waves) stages each filter chunk once per 512 pixels instead of once per 128 (105.8 -> 71.8 us)
         const bool wide_k = p.Co <= 32 && p.Ci >= 128 && p.stride == 1 && p.ks == 3 && !p.stuff && !p.wg_partial && (int64_t)p.B * p.Ho * p.Wo >= 65536;
         const bool c32 = p.wg_partial || (!getenv("STL_CONV_NO_C32_SHAPE4") && p.Co <= s4_maxco && p.stride == 1 && p.ks == 3 && !wide_k);
-        if (shape == 4 && !c32) continue;
-        if (c32 && shape != 4) continue;
+        // ... and 256 px x 32 co blocks of 8 waves (shape 8) win END TO END although they lose in isolation (C = 32 at
+        // 96x72: 19.8 vs 17.9 us alone, 16.27 vs 16.47 ms per step): two 128-pixel halves share one copy of the filters
+        // and one halo tile, i.e. fewer bytes per launch and half as many blocks competing for the CUs.  Shape 4 stays
+        // the fallback where no 256-pixel tile fits (small maps) and for the fused backward.
+        static const int c32shape = getenv("STL_CONV_C32_SHAPE") ? atoi(getenv("STL_CONV_C32_SHAPE")) : 8;
+        if ((shape == 4 || shape == 8) && !c32) continue;
+        if (c32 && shape != 4 && shape != 8) continue;
+        if (c32 && shape == 8 && (p.wg_partial || c32shape != 8)) continue;
         if (wide_k && shape != 1) continue;
         // kernel family: measured on MI355X (tools/conv_probe6.py; end to end the threshold Co >= 256 is the better one) the wave-specialised kernel wins for
         // stride-2 convs and for the small, deep maps (Co >= 256), the uniform kernel elsewhere
@@ -739,6 +750,7 @@ Plan choose_plan(const stl_conv& p, int ck) {
             if (p.wg_partial && nva > 3) continue;   // fused backward: one instantiation (3 staging vectors per thread)
             const size_t lds = lds_bytes(p, shape, th, tw, ck, nullptr);
             if (shape == 4 && !p.wg_partial && lds > 40 * 1024 && nva <= 3) continue;  // keep four blocks per CU
+            if (shape == 8 && lds > 80 * 1024) continue;                               // ... resp. two 8-wave blocks
             if (lds > 158 * 1024) continue;
             const double tiles = (double)ceil_div(vrows, th) * ceil_div(p.Wo, tw);
             // cost model (arbitrary units): MFMA work of all launched tiles (padding included), the
@@ -749,6 +761,7 @@ Plan choose_plan(const stl_conv& p, int ck) {
             double cost = (mfma > bytes ? mfma : bytes) + 0.3 * (mfma < bytes ? mfma : bytes);
             const double waves = blocks * sh.thr / 64.0;
             if (waves < 2048.0) cost *= 1.0 + 0.15 * (2048.0 / waves - 1.0 > 4.0 ? 4.0 : 2048.0 / waves - 1.0);
+            if (c32 && shape == 4 && c32shape == 8 && !p.wg_partial) cost *= 4.0;   // fallback only
             if (cost < best.cost) best = Plan{shape, th, tw, lds, cost};
         }
     }
@@ -880,6 +893,7 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     static const int cap4 = getenv("STL_CONV_GRID_CAP4") ? atoi(getenv("STL_CONV_GRID_CAP4")) : 768;   // 1024 -> 768: 16.62 -> 16.56 ms/step (three resident blocks per CU leave room for the co-running kernels)
     static const int cap8 = getenv("STL_CONV_GRID_CAP8") ? atoi(getenv("STL_CONV_GRID_CAP8")) : 256;
     int cap = sh.ws ? 256 : (sh.thr == 512 ? cap8 : cap4);
+    if (plan.shape == 8) cap = getenv("STL_CONV_GRID_CAP_S8") ? atoi(getenv("STL_CONV_GRID_CAP_S8")) : cap4 / 2;   // two 8-wave blocks per CU
     if (!getenv("STL_CONV_CAP_PER_TILE")) cap = std::max(8, (cap / k.ny + 7) / 8 * 8);
     if (const char* e = getenv("STL_CONV_GRID_CAP")) cap = atoi(e) > 0 ? (atoi(e) + 7) / 8 * 8 : cap;
     if (gx > cap) gx = cap;
