@@ -728,7 +728,7 @@ Plan choose_plan(const stl_conv& p, int ck) {
         // the fallback where no 256-pixel tile fits (small maps) and for the fused backward.
         static const int c32shape = getenv("STL_CONV_C32_SHAPE") ? atoi(getenv("STL_CONV_C32_SHAPE")) : 8;
         if ((shape == 4 || shape == 8) && !c32) continue;
-        if (c32 && shape != 4 && shape != 8) continue;
+        if (c32 && shape != 4 && shape != 8 && !(shape == 1 && c32shape == 1)) continue;
         if (c32 && shape == 8 && (p.wg_partial || c32shape != 8)) continue;
         if (wide_k && shape != 1) continue;
         // kernel family: measured on MI355X (tools/conv_probe6.py; end to end the threshold Co >= 256 is the better one) the wave-specialised kernel wins for
@@ -761,7 +761,7 @@ Plan choose_plan(const stl_conv& p, int ck) {
             double cost = (mfma > bytes ? mfma : bytes) + 0.3 * (mfma < bytes ? mfma : bytes);
             const double waves = blocks * sh.thr / 64.0;
             if (waves < 2048.0) cost *= 1.0 + 0.15 * (2048.0 / waves - 1.0 > 4.0 ? 4.0 : 2048.0 / waves - 1.0);
-            if (c32 && shape == 4 && c32shape == 8 && !p.wg_partial) cost *= 4.0;   // fallback only
+            if (c32 && shape == 4 && c32shape != 4 && !p.wg_partial) cost *= 4.0;   // fallback only
             if (cost < best.cost) best = Plan{shape, th, tw, lds, cost};
         }
     }
