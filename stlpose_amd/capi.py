@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STLPOSE_HIP_LIB") or os.path.join(_HERE, "libstlpose_hip.so")   # override: A/B of two builds
 
 F32, BF16 = 0, 1
-NSHARD = 8
+NSHARD = 2
 SRC_PLAIN, SRC_BN, SRC_BNBWD = 0, 1, 2
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
