@@ -305,6 +305,15 @@ int stl_program_destroy(void* program);
  * communication stream picks up a finished gradient bucket. */
 int stl_program_wait_op(void* program, int op, void* stream);
 
+/* Streams restricted to a set of compute units (hipExtStreamCreateWithCUMask): mask bit i = CU i of the driver's
+ * enumeration.  The reference runs the branches of an exchange module one after the other (HRnet.py:252-253) and
+ * leaves the overlap of the weight gradients with the data-gradient chain to cuDNN / the autograd engine; here the
+ * planner places them explicitly, and a masked stream bounds the share of the chip the off-chain work may take. */
+int stl_stream_create_masked(const uint32_t* mask, int nwords, void** out_stream);
+int stl_stream_destroy(void* stream);
+/* Debug: out[2b] = XCC id, out[2b+1] = HW_ID register of block b (64 threads, spins spin_ticks of the 100 MHz clock). */
+int stl_probe_placement(uint32_t* out, int nblocks, int spin_ticks, void* stream);
+
 /* Self-checks that need no reference: MFMA / LDS-transpose lane maps (used by tests). */
 int stl_selftest_mfma(float* out /* [4] max abs err: bf16 mfma, f32 mfma, tr-read, f64 atomic */, void* stream);
 

@@ -210,3 +210,42 @@ def synth_state_dict(model: nn.Module, seed: int = 0) -> Dict[str, torch.Tensor]
 def load_synth(model: nn.Module, seed: int = 0) -> nn.Module:
     model.load_state_dict(synth_state_dict(model, seed), strict=True)
     return model
+
+
+# ----------------------------------------------------------------------------------------
+# bf16-STORAGE emulation (calibration of the bf16 path's parity bar, tests only).
+# The HIP bf16 path keeps activations and kernel-layout weights in bf16 and accumulates in
+# fp32.  The same rounding points are imposed on this fp32 oracle with hooks: every conv
+# (the head excepted: fp32 weights, fp32 output) sees its input and its weight rounded to
+# bf16 and has its raw output rounded to bf16 before the BatchNorm reads it.  The distance of
+# that run from the plain fp32 oracle is what bf16 STORAGE costs on a given batch -- the HIP
+# path is held to a small multiple of it, not to a free constant.
+# ----------------------------------------------------------------------------------------
+class bf16_storage:
+    def __init__(self, model: nn.Module):
+        self.model, self.handles, self.saved = model, [], {}
+
+    @staticmethod
+    def _r(t: torch.Tensor) -> torch.Tensor:
+        return t.to(torch.bfloat16).to(t.dtype)
+
+    def __enter__(self):
+        for name, m in self.model.named_modules():
+            if not isinstance(m, nn.Conv2d):
+                continue
+            head = name == "final_layer"
+            self.handles.append(m.register_forward_pre_hook(lambda mod, args: (self._r(args[0]),)))
+            if not head:
+                self.saved[name] = m.weight.data
+                m.weight.data = self._r(m.weight.data)
+                self.handles.append(m.register_forward_hook(lambda mod, args, out: self._r(out)))
+        return self.model
+
+    def __exit__(self, *exc):
+        for h in self.handles:
+            h.remove()
+        mods = dict(self.model.named_modules())
+        for name, w in self.saved.items():
+            mods[name].weight.data = w
+        self.handles, self.saved = [], {}
+        return False

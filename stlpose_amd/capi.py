@@ -144,6 +144,9 @@ SIGNATURES = {
     "stl_program_destroy": [vp],
     "stl_program_wait_op": [vp, i32, vp],
     "stl_selftest_mfma": [vp, vp],
+    "stl_stream_create_masked": [vp, i32, C.POINTER(vp)],
+    "stl_stream_destroy": [vp],
+    "stl_probe_placement": [vp, i32, i32, vp],
     "stl_version": [],
 }
 

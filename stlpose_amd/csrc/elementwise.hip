@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* master, T
     const int t = e.ks * e.ks;
     const int64_t tot = (int64_t)e.Co * e.Ci * t;
     const int64_t base = (int64_t)(bx - e.blk0) * 1024;
-    if (!e.patch && (e.Ci & 3) == 0 && (e.Co & 3) == 0 && t <= 9) {
+    if (!e.patch && (e.Ci & 3) == 0 && (e.Co & 3) == 0 && t <= 9 && e.Cip == e.Ci && (e.fwd_off & 3) == 0 && (e.bwd_off < 0 || (e.bwd_off & 3) == 0)) {   // row pitch Ci, 8/16-byte aligned vector stores
         // 32 x 32 channel tiles through LDS: the OIHW master is read ONCE in contiguous (32 ci x taps) row segments,
         // both kernel layouts are written in 4-element vectors that form 64-byte runs ([co][tap][ci0..ci0+32) and
         // [ci][flipped tap][co0..co0+32)).  The table still counts 1024-element blocks per conv; the blocks of a conv

@@ -150,7 +150,7 @@ class Engine:
         self._keep: List = []  # keep ctypes structs / tensors alive
         self._progs: Dict[int, Tuple] = {}
         self.act_bytes = 0
-        self.generation = 0   # forward passes seen by the autograd bridge (hrnet._Fn stale-backward check)
+        self.generation = 0   # forward passes through this plan (hrnet._Fn stale-backward check)
         # static I/O
         self.img = torch.zeros(B, 3, H, W, dtype=torch.float32, device=self.dev)
         self.out: Optional[torch.Tensor] = None
@@ -170,6 +170,7 @@ class Engine:
         self.nwstreams = 0 if not self.wgrad_streams else (int(wgs[1:]) if wgs.startswith("n") else self.nstreams)
         self._stream = 0
         self._side = None
+        self._chain_mask = bool(os.environ.get("STLPOSE_CUMASK_CHAIN", ""))
         self._stats_used = 0
         self._wk_elems = 0
         self._wk_fix: List[Tuple] = []
@@ -546,7 +547,7 @@ class Engine:
             self._nactive.setdefault(id(o[1]), cur_active)
         assert bk["done"] == 0 and bk["hi"] == 0, "gradient buckets do not cover the parameter buffer"
         # slab arena + reduce table
-        self.slab_arena = torch.empty(max(self._slab_elems, 1), dtype=torch.float32, device=self.dev)
+        self.slab_arena = torch.zeros(max(self._slab_elems, 1), dtype=torch.float32, device=self.dev)
         base = self.slab_arena.data_ptr()
         hb, off = self._head_bwd_args
         hb.partial = base + 4 * off
@@ -711,7 +712,8 @@ class Engine:
         self._slab_elems += (wg.nsplit * nel + 3) // 4 * 4
         self.slabs.append(dict(part_off=part_off, grad_off=ci.master_off, nsplit=wg.nsplit, Co=ci.Co, Ci=ci.Ci,
                                ks=ci.ks, Cip=ci.Cik, patch=int(ci.patch), stride=0, struct=wg))
-        ops.append(("stl_conv_wgrad", wg, wstrm, [y.dt.data_ptr(), x.ptr], [id(wg)]))
+        if os.environ.get("STLPOSE_SKIP_WGRAD", "0") == "0":   # calibration only ("1": no weight-gradient launches, slabs stay zero)
+            ops.append(("stl_conv_wgrad", wg, wstrm, [y.dt.data_ptr(), x.ptr], [id(wg)]))
         bk["reads"].append(id(wg))
         bk["strm"] = wstrm
 
@@ -774,8 +776,11 @@ class Engine:
                 for j, wv in enumerate(waits[i]):
                     o.wait[j] = wv
                 o.record = int(i in need)
+            if self._chain_mask:   # every op on a masked stream of its own; streams[0] (the caller's) only forks / joins
+                for i in range(len(ops)):
+                    arr[i].stream += 1
             h = C.c_void_p()
-            capi.call("stl_program_create", arr, len(ops), self.total_streams, C.byref(h))
+            capi.call("stl_program_create", arr, len(ops), self.total_streams + (1 if self._chain_mask else 0), C.byref(h))
             prog = self._progs[key] = (h, arr)
         return prog[0]
 
@@ -789,14 +794,48 @@ class Engine:
         cross-stream dependencies are HIP events inside stl_program_run."""
         h = self._program(ops)
         if self._side is None:
-            self._side = [torch.cuda.Stream(device=self.dev) for _ in range(self.total_streams - 1)]
-            self._stream_arr = (C.c_void_p * self.total_streams)()
-            for i, s_ in enumerate(self._side):
-                self._stream_arr[i + 1] = s_.cuda_stream
+            self._make_streams()
         self._stream_arr[0] = stream
         rc = self.lib.stl_program_run(h, self._stream_arr)
         if rc != 0:
             raise RuntimeError(f"stl_program_run: {self.lib.stl_last_error().decode()}")
+
+    @staticmethod
+    def _cu_range(spec: str):
+        """'lo:hi' -> ctypes uint32[8] with bits lo..hi-1 set (256 CUs), or None for an empty spec."""
+        if not spec:
+            return None
+        lo, hi = (int(v) for v in spec.split(":"))
+        assert 0 <= lo < hi <= 256, f"CU range {spec!r} outside 0..256"
+        words = (C.c_uint32 * 8)()
+        for i in range(lo, hi):
+            words[i >> 5] |= 1 << (i & 31)
+        return words
+
+    def _make_streams(self):
+        """HIP streams of the program: index 0 is the caller's stream; 1 .. nstreams-1 the other branch streams;
+        nstreams .. the off-chain (weight-gradient) streams when STLPOSE_WGRAD_STREAMS asks for them.
+        STLPOSE_CUMASK_OFF='lo:hi' restricts the off-chain streams to those compute units, STLPOSE_CUMASK_CHAIN='lo:hi'
+        the branch streams (then ALL ops run on masked streams and the caller's stream only forks / joins)."""
+        off = 1 if self._chain_mask else 0
+        n = self.total_streams + off
+        self._stream_arr = (C.c_void_p * n)()
+        self._side = []
+        m_off = self._cu_range(os.environ.get("STLPOSE_CUMASK_OFF", ""))
+        m_chain = self._cu_range(os.environ.get("STLPOSE_CUMASK_CHAIN", ""))
+        with torch.cuda.device(self.dev):
+            for i in range(1, n):
+                op_stream = i - off                     # index in the planner's numbering
+                mask = m_chain if op_stream < self.nstreams else m_off
+                if mask is not None:
+                    h = C.c_void_p()
+                    capi.call("stl_stream_create_masked", mask, 8, C.byref(h))
+                    self._side.append(h)                # lives as long as the engine
+                    self._stream_arr[i] = h.value
+                else:
+                    s_ = torch.cuda.Stream(device=self.dev)
+                    self._side.append(s_)
+                    self._stream_arr[i] = s_.cuda_stream
 
     def prep_weights(self, stream: int):
         st = self.store
@@ -820,6 +859,7 @@ class Engine:
 
     def forward(self, stream: int, update_running: bool = True):
         """weights -> kernel layout, zero statistics, forward program, running-stat update."""
+        self.generation += 1   # every pass overwrites the plan's activations (hrnet._Fn stale-backward check)
         if not self.weights_ready:
             self.prep_weights(stream)
         self.weights_ready = False

@@ -64,8 +64,8 @@ class _Fn(torch.autograd.Function):
         ctx.net, ctx.eng = net, eng
         out = torch.ops.stlpose.hrnet_forward(img, ops.register_engine(eng))   # custom op: the planned forward program
         # The activations backward needs live in the engine's planned buffers, not in ctx: a later
-        # forward through the same plan overwrites them.  Remember which forward this node belongs to.
-        eng.generation += 1
+        # forward through the same plan overwrites them.  Remember which forward this node belongs to
+        # (Engine.forward counts EVERY pass through the plan, also no-grad ones and TrainStep's).
         ctx.generation = eng.generation
         return out
 
@@ -79,8 +79,8 @@ class _Fn(torch.autograd.Function):
                 "differentiated, and its activations were overwritten (the reference's autograd keeps one set "
                 "per call; this engine keeps one per plan).  Call backward before the next forward of the same "
                 "shape, or concatenate the inputs into one batch.")
-        torch.ops.stlpose.hrnet_backward(gout.contiguous(), ops.register_engine(eng))   # fills the flat gradient buffer
-        net._publish_grads()
+        flat = torch.ops.stlpose.hrnet_backward(gout.contiguous(), ops.register_engine(eng))   # the flat parameter gradient
+        net._publish_grads(flat)
         return None, None, None, None
 
 
@@ -143,7 +143,7 @@ class PoseHighResolutionNet(nn.Module):
 
     def _pack(self, device):
         """(Re)point every parameter/buffer at its slice of the flat fp32 storage on `device`."""
-        if getattr(self, "_pinned_by", None) is not None:
+        if self._holder() is not None:
             raise RuntimeError(
                 "stlpose_amd.PoseHighResolutionNet: the flat parameter storage is held by a TrainStep / Trainer "
                 f"on {self._store.device}; re-packing it for {device} would silently detach the optimiser from the "
@@ -173,19 +173,33 @@ class PoseHighResolutionNet(nn.Module):
         self._engines.clear()
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
 
-    def _publish_grads(self):
-        """Expose the gradients as per-parameter ``.grad`` views of one flat tensor (the engine's own
-        buffer is overwritten by the next backward, so publish a copy); accumulates when the
-        caller has not zeroed its gradients, like autograd would."""
+    def _holder(self):
+        """The live TrainStep / Trainer that owns the flat storage, or None (the reference is weak: a dropped
+        TrainStep releases the model)."""
+        ref = self.__dict__.get("_pinned_by")
+        return ref() if ref is not None else None
+
+    def __getstate__(self):   # torch.save(model) / pickle: the weak reference and the device plans stay behind
+        d = dict(self.__dict__)
+        for k in ("_pinned_by", "_engines", "_store", "_anchor", "_grad_pub"):
+            d.pop(k, None)
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self._store, self._engines, self._anchor = None, {}, None
+
+    def _publish_grads(self, flat: torch.Tensor):
+        """Expose the gradients as per-parameter ``.grad`` views of one flat tensor (`flat`: the copy of the engine's
+        gradient buffer the backward op returned; the engine's own buffer is overwritten by the next backward);
+        accumulates when the caller has not zeroed its gradients, like autograd would."""
         st = self._store
         pub = getattr(self, "_grad_pub", None)
-        if pub is None or pub.device != st.grads.device or pub.shape != st.grads.shape:
-            pub = self._grad_pub = torch.zeros_like(st.grads)
         first = self._tensor(self._reg.params[0][0]).grad
-        if first is not None and first.data_ptr() == pub.data_ptr():
-            pub.add_(st.grads)       # gradient accumulation across backward calls
+        if pub is not None and first is not None and first.data_ptr() == pub.data_ptr():
+            pub.add_(flat)       # gradient accumulation across backward calls
             return
-        pub.copy_(st.grads)
+        pub = self._grad_pub = flat
         for key, shape in self._reg.params:
             off = st.param_off[key]
             self._tensor(key).grad = pub[off:off + int(math.prod(shape))].view(shape)

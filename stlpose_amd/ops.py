@@ -137,11 +137,19 @@ def _hrnet_bwd(grad_out: torch.Tensor, handle: int) -> torch.Tensor:
     eng = _ENGINES[handle]
     eng.dout.copy_(grad_out)
     eng.backward(_st())
-    return eng.store.grads
+    return eng.store.grads.clone()   # a fresh tensor: an op must not hand out an alias of the plan's own buffer
 
 
-_define("hrnet_forward(Tensor img, int engine) -> Tensor", _hrnet_fwd,
-        lambda img, engine: img.new_empty(img.shape[0], 17, img.shape[2] // 4, img.shape[3] // 4))
-_define("hrnet_backward(Tensor grad_out, int engine) -> Tensor", _hrnet_bwd)
+def _hrnet_fwd_fake(img, engine):
+    eng = _ENGINES[engine]   # joints and output stride come from the planned engine, not from constants
+    return img.new_empty(tuple(eng.out.shape), dtype=torch.float32)
+
+
+def _hrnet_bwd_fake(grad_out, engine):
+    return grad_out.new_empty(_ENGINES[engine].store.nparam, dtype=torch.float32)
+
+
+_define("hrnet_forward(Tensor img, int engine) -> Tensor", _hrnet_fwd, _hrnet_fwd_fake)
+_define("hrnet_backward(Tensor grad_out, int engine) -> Tensor", _hrnet_bwd, _hrnet_bwd_fake)
 
 OPS = ["person_mse", "heatmap_argmax", "final_preds", "flip_merge", "gaussian_targets", "affine_crop", "hrnet_forward", "hrnet_backward"]

@@ -81,8 +81,11 @@ class TrainStep:
         ``apply_perceptual_loss`` (lib/loss.py:97-150; 'add': scale = 1 + mean(p); lambda form: scale =
         lambda_D, offset = lambda_P * mean(p)).  The scale multiplies dL/dout inside the loss kernel."""
         scale, offset = float(scale), float(offset)
-        if self.use_graph and self._g_fb is not None and (scale, offset) != (self._loss_scale, self._loss_offset):
-            self._g_fb = self._g_opt = None   # the scale is a kernel argument baked into the capture
+        if self.use_graph and (scale, offset) != (self._loss_scale, self._loss_offset):
+            # the scale is a kernel argument baked into the capture and changes per batch with the perceptual loss
+            # (scale = 1 + mean(p)): re-capturing every step would cost a device sync each time -- leave graph mode
+            self.use_graph = False
+            self._g_fb = self._g_opt = None
         self._loss_scale, self._loss_offset = scale, offset
 
     def load_batch(self, img: torch.Tensor, target: torch.Tensor, target_weight: torch.Tensor):
@@ -94,13 +97,13 @@ class TrainStep:
         """Call after changing the model's parameters outside of step() (load_state_dict, manual edits)."""
         self._prepped = False
 
-    def _fwd_bwd(self):
+    def _fwd_bwd(self, update_running: bool = True):
         st = torch.cuda.current_stream().cuda_stream
         e = self.eng
         # kernel-layout weights were refreshed bucket by bucket at the end of the previous step
         e.weights_ready = getattr(self, "_prepped", False)
         self._prepped = False
-        e.forward(st)
+        e.forward(st, update_running=update_running)
         B, J = e.out.shape[:2]
         capi.call("stl_mse_loss", e.out.data_ptr(), self.target.data_ptr(), self.tweight.data_ptr(), e.dout.data_ptr(),
                   self._partial.data_ptr(), self._nblk, self.loss.data_ptr(), B, J, e.out[0, 0].numel(),
@@ -168,8 +171,8 @@ class TrainStep:
     def _capture(self):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):   # warm-up outside capture (lazy kernel attributes, allocator)
-            self._fwd_bwd()
+        with torch.cuda.stream(side):   # warm-up outside capture (lazy kernel attributes, allocator); the BatchNorm
+            self._fwd_bwd(update_running=False)   # running statistics and num_batches_tracked must not see this extra pass
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._g_fb = torch.cuda.CUDAGraph()
@@ -178,7 +181,6 @@ class TrainStep:
         self._g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_opt):
             self._optim()
-        # the warm-up pass updated BN running stats once; harmless for training, documented
 
     # ------------------------------------------------------------------ one step
     def step(self) -> torch.Tensor:
