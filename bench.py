@@ -73,31 +73,32 @@ def time_dominant_kernel(ts):
                 launches=len(evs), ms=tot_ms / len(evs), tflops=flops / tot_ms / 1e9, gbs=bytes_alg / tot_ms / 1e6)
 
 
-def cpu_baseline(arch, H, W, seconds=20.0):
-    """The oracle (plain torch fp32 restatement of the reference graph) timed on the host cores."""
+def cpu_baseline(arch, H, W, batch=32, steps=3, adam=True):
+    """The oracle (plain torch fp32 restatement of the reference graph) timed on the host cores at the benchmarked
+    batch size (bs 32 forward + MSE + backward for a like-for-like ratio; the Adam step is in the timed
+    region like in the GPU line).  Bounded sample: `steps` steps (~7 s each at W32 384x288 on 16 threads), median of
+    all but the first."""
     from oracle import hrnet_ref, pose_ref
     torch.manual_seed(0)
     torch.set_num_threads(min(16, os.cpu_count() or 1))  # the GPU box's CPU share for one GPU
-    B = 8
+    B = batch
     m = hrnet_ref.RefPoseNet(arch).train()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3) if adam else None
     img = torch.randn(B, 3, H, W)
     tgt = torch.rand(B, 17, H // 4, W // 4)
     tw = torch.ones(B, 17, 1)
     times = []
-    t_end = time.time() + seconds
-    while time.time() < t_end or len(times) < 2:
+    for _ in range(max(steps, 2)):
         t0 = time.time()
-        opt.zero_grad()
+        m.zero_grad(set_to_none=True)
         loss = pose_ref.person_mse_loss(m(img), tgt, tw)
         loss.backward()
-        opt.step()
+        if opt is not None:
+            opt.step()
         times.append(time.time() - t0)
-        if len(times) >= 12:
-            break
-    med = float(np.median(times[1:])) if len(times) > 1 else times[0]
-    return dict(value=B / med, unit="images/sec", cores=torch.get_num_threads(), kind="port",
-                sample=f"oracle RefPoseNet({arch}) fp32 {H}x{W} bs{B} fwd+MSE+bwd+Adam, median of {max(len(times) - 1, 1)} steps")
+    med = float(np.median(times[1:]))
+    return dict(value=round(B / med, 3), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle RefPoseNet({arch}) fp32 {H}x{W} bs{B} fwd+MSE+bwd{'+Adam' if adam else ''}, median of {len(times) - 1} steps after one warm-up step")
 
 
 def cpu_baseline_cfg1(seconds=8.0):
@@ -154,6 +155,85 @@ def extra_fp32_path(arch, batch, H, W, dev, steps=6, warmup=2):
                 roofline=dict(bound="mfma", achieved=round(tf, 2) if tf else None, peak=157.3, unit="TFLOP/s",
                               frac=round(tf / 157.3, 4) if tf else None, traffic=None,
                               note="whole step against the fp32-input MFMA peak (v_mfma_f32_16x16x4_f32)"))
+
+
+def extra_train_leg(arch, batch, H, W, dev, steps=20, warmup=6, cpu_batch=8):
+    """The same train step (bf16, fwd + MSE + bwd + Adam) at another configuration of BASELINE.json's list: W32 256x192
+    (north_star: "throughput on synthetic 256x192 and 384x288 batches") and W48 384x288 (configs[2]'s shape on one GPU)."""
+    from stlpose_amd import PoseHighResolutionNet
+    from stlpose_amd.train_step import TrainStep
+    torch.manual_seed(0)
+    model = PoseHighResolutionNet(arch, "bf16").to(dev)
+    ts = TrainStep(model, batch, H, W, optimizer="adam", lr=1e-3, device=dev)
+    ts.load_batch(*synth_batch(batch, H, W, 0, dev, sigma=3.0 if H >= 384 else 2.0))
+    for _ in range(warmup):
+        ts.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ts.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    loss = float(ts.loss.item())
+    fl = FLOPS_PER_IMG[(arch, H, W)]
+    tf = batch / dt * fl / 1e12
+    del ts, model
+    torch.cuda.empty_cache()
+    out = dict(metric=f"images/sec/GPU HRNet-{arch.upper()} {H}x{W} bs={batch} train step (fwd+MSE+bwd+Adam)", value=round(batch / dt, 2),
+               unit="images/sec", ms_per_step=round(dt * 1e3, 3), dtype="bf16", steps=steps, warmup=warmup, loss=loss,
+               roofline=dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_PEAK_BF16, unit="TFLOP/s", frac=round(tf / MFMA_PEAK_BF16, 4),
+                             traffic=None, note="whole step: algorithmic conv FLOPs (SURVEY 8(d)) / step time"))
+    if cpu_batch:
+        out["cpu_baseline"] = cpu_baseline(arch, H, W, batch=cpu_batch, steps=2)
+    return out
+
+
+def extra_eval_path(dev, batches=10, batch=32, H=384, W=288, persons_per_image=4):
+    """SURVEY 8(d)'s substitute for configs[4] (end-to-end OKS needs real data): the evaluation path of
+    03_evaluate.py:132-188 on a synthetic checkpoint -- per batch flip-test forward x 2, flip_back + average on the
+    device, loss, PCK, quarter-pixel decode + inverse affine; then box re-scoring and OKS-NMS over all persons.  Timed
+    through stlpose_amd.evaluate.Evaluator itself, host post-processing included."""
+    from stlpose_amd import PoseHighResolutionNet
+    from stlpose_amd.evaluate import Evaluator
+    torch.manual_seed(0)
+    model = PoseHighResolutionNet("w32", "bf16").to(dev).eval()
+    img, tgt, tw = synth_batch(batch, H, W, 0, dev, sigma=3.0)
+    rng = np.random.Generator(np.random.PCG64(5))
+
+    def loader(n):
+        for bi in range(n):
+            ids = (bi * batch + np.arange(batch)) // persons_per_image
+            meta = dict(center=rng.uniform(100, 400, (batch, 2)), scale=rng.uniform(0.8, 2.0, (batch, 2)), score=rng.uniform(0.3, 1.0, batch),
+                        image_id=ids)
+            yield img, tgt, tw, meta
+    ev = Evaluator(model, device=dev, flip=True)
+    ev.evaluate_model(loader(2))   # warm-up: plan + lazy kernel attributes
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = ev.evaluate_model(loader(batches))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = batches * batch
+    tf = n / dt * 2 * 34.403e9 / 1e12     # two forward passes per image (SURVEY appendix A: F_fwd 34.403 GFLOP at 384x288)
+    out = dict(metric="images/sec evaluation path HRNet-W32 384x288 bs=32: flip-test forward x2 + flip_merge + loss + PCK + final_preds + rescoring / OKS-NMS",
+               value=round(n / dt, 2), unit="images/sec", ms_per_batch=round(dt / batches * 1e3, 3), dtype="bf16", batches=batches,
+               results=len(res.get("results", [])) if isinstance(res, dict) else None,
+               roofline=dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_PEAK_BF16, unit="TFLOP/s", frac=round(tf / MFMA_PEAK_BF16, 4), traffic=None,
+                             note="2 x forward conv FLOPs per image / wall time, host post-processing included"))
+    del ev, model
+    torch.cuda.empty_cache()
+    # CPU baseline: the oracle's flip-test forward + decode + NMS on a bounded sample (4 images)
+    from oracle import hrnet_ref, pose_ref
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref = hrnet_ref.RefPoseNet("w32").eval()
+    x = torch.randn(4, 3, H, W)
+    t0 = time.time()
+    with torch.no_grad():
+        o = pose_ref.forward_pass(ref, x, flip=True).numpy()
+    pose_ref.final_preds(o, np.full((4, 2), 200.0), np.full((4, 2), 1.2))
+    out["cpu_baseline"] = dict(value=round(4 / (time.time() - t0), 3), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                               sample="oracle flip-test forward + final_preds, 4 images of 3x384x288, one evaluation")
+    return out
 
 
 def _he_weights(convs, seed):
@@ -282,6 +362,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
+    if world == 1 and os.environ.get("STLPOSE_DP_FORCE", "0") == "1":   # one-rank rehearsal of the bucketed all-reduce path
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group(os.environ.get("STL_DIST_BACKEND", "nccl"), rank=0, world_size=1)
+        pg = dist.group.WORLD
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -322,10 +408,48 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
     loss = float(ts.loss.item())
+    comm = None
+    if world > 1 or ts._force_dp:
+        # Self-describing multi-GPU line: what the communicator reports, each gradient bucket's all-reduce alone
+        # (HIP events around the collective, nothing else in flight), and the step with the collectives switched off
+        # -- exposed communication = ms_per_step - ms_per_step_no_comm.  Every rank runs the same sequence.
+        import torch.distributed as dist
+        per_bucket = []
+        for i, b in enumerate(ts.dp.buckets):
+            barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                ts.dp.reduce_bucket(i, force=True)
+            e1.record()
+            torch.cuda.synchronize()
+            per_bucket.append(dict(mbytes=round(b.numel() * (2 if ts.dp.bf16 else 4) / 2 ** 20, 2), allreduce_ms=round(e0.elapsed_time(e1) / 3, 4)))
+        dp_saved, force_saved = ts.dp, ts._force_dp
+        ts.dp, ts._force_dp = None, False
+        nc = max(5, min(a.steps, 20))
+        with ctx:
+            for _ in range(3):
+                ts.step()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(nc):
+                ts.step()
+            barrier()
+            dt_nc = (time.perf_counter() - t1) / nc
+        ts.dp, ts._force_dp = dp_saved, force_saved
+        tt = torch.tensor([dt_nc], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        comm = dict(world=dist.get_world_size() if dist.is_initialized() else 1, backend=dist.get_backend() if dist.is_initialized() else None,
+                    bf16_buckets=bool(ts.dp.bf16), buckets=per_bucket, gradient_mbytes=round(ts.store.nparam * 4 / 2 ** 20, 1),
+                    ms_per_step_no_comm=round(float(tt.item()) * 1e3, 3),
+                    exposed_comm_ms=round(dt / a.steps * 1e3 - float(tt.item()) * 1e3, 3))
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        if comm is not None:
+            comm["exposed_comm_ms"] = round(dt / a.steps * 1e3 - comm["ms_per_step_no_comm"], 3)
     ms = dt / a.steps * 1e3
     value = a.batch * world * a.steps / dt
 
@@ -336,14 +460,14 @@ def main():
         if dom:
             # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
             # (tools/pmc_traffic.py -> profiles/r*_pmc_wgrad.json); null if they describe another config
-            traffic = None
+            traffic = traffic_src = None
             import glob
             for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_wgrad.json"))):
                 try:
                     rec = json.load(open(f))
                     if rec.get("launches") == dom["launches"] and (a.arch, a.height, a.width, a.batch, a.dtype) == ("w32", 384, 288, 32, "bf16") \
                             and rec.get("fused_bwd", "0") == os.environ.get("STLPOSE_FUSED_BWD", "0"):
-                        traffic = round(rec["traffic_bytes_per_launch"])
+                        traffic, traffic_src = round(rec["traffic_bytes_per_launch"]), "profiles/" + os.path.basename(f)
                 except Exception:
                     pass
             roof = dict(bound="mfma", achieved=round(dom["tflops"], 2), peak=MFMA_PEAK_BF16, unit="TFLOP/s",
@@ -351,7 +475,8 @@ def main():
                         launches_per_step=dom["launches"], avg_launch_us=round(dom["ms"] * 1e3, 2),
                         algorithmic_GBps=round(dom["gbs"], 1), hbm_frac=round(dom["gbs"] / HBM_PEAK, 4),
                         algorithmic_bytes_per_launch=round(dom["gbs"] * dom["ms"] * 1e6),
-                        traffic_unit="HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)")
+                        traffic_unit="HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)",
+                        traffic_source=(traffic_src + " (rocprofv3 --pmc passes of this command, committed; not measured in this run)") if traffic_src else None)
         out = dict(metric=f"images/sec/GPU HRNet-{a.arch.upper()} {a.height}x{a.width} train step; PCKh@0.5 parity", value=round(value, 2),
                    unit="images/sec", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.dtype, data="synthetic",
@@ -362,11 +487,16 @@ def main():
                    step_tflops=round(value * flops_img / 1e12, 2) if flops_img else None,
                    step_mfma_frac=round(value / world * flops_img / 1e12 / MFMA_PEAK_BF16, 4) if flops_img else None,
                    roofline=roof)
+        if comm is not None:
+            out["comm"] = comm
         if world == 1 and not a.no_extras:
             del ts, model
             torch.cuda.empty_cache()
             extras = {}
-            for name, fn in (("fp32_path", lambda: extra_fp32_path(a.arch, a.batch, a.height, a.width, dev)),
+            for name, fn in (("w32_256x192", lambda: extra_train_leg("w32", a.batch, 256, 192, dev)),
+                             ("w48_384x288", lambda: extra_train_leg("w48", a.batch, 384, 288, dev, steps=12, warmup=4)),
+                             ("eval_path", lambda: extra_eval_path(dev)),
+                             ("fp32_path", lambda: extra_fp32_path(a.arch, a.batch, a.height, a.width, dev)),
                              ("vgg_cfg4", lambda: extra_vgg_cfg4(dev)), ("vgg19_style_cfg4", lambda: extra_vgg19_style(dev))):
                 try:
                     extras[name] = fn()
@@ -378,7 +508,7 @@ def main():
             if not a.no_extras:
                 out["cpu_baseline"]["cfg1"] = cpu_baseline_cfg1()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or pg is not None:
         torch.distributed.destroy_process_group()
 
 

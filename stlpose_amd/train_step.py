@@ -25,7 +25,7 @@ class TrainStep:
     def __init__(self, model: PoseHighResolutionNet, batch: int, height: int, width: int, optimizer: str = ADAM,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  momentum: float = 0.9, nesterov: bool = False, process_group=None, bucket_mb: float = 32.0,
-                 use_graph: bool = True, device=None):
+                 use_graph: bool = True, device=None, bf16_buckets: Optional[bool] = None):
         self.model = model
         from .hrnet import norm_device
         dev = norm_device(device or "cuda")
@@ -41,7 +41,10 @@ class TrainStep:
         self.kind = optimizer
         self.pg = process_group
         # buckets = the engine's own gradient buckets (contiguous slices, final at known points of backward)
-        self.dp = (FlatAllReduce(self.store.grads, process_group, bucket_mb, bounds=[(b["lo"], b["hi"]) for b in self.eng.buckets])
+        if bf16_buckets is None:
+            bf16_buckets = os.environ.get("STLPOSE_BF16_BUCKETS", "0") != "0"
+        self.dp = (FlatAllReduce(self.store.grads, process_group, bucket_mb, bounds=[(b["lo"], b["hi"]) for b in self.eng.buckets],
+                                 bf16_buckets=bf16_buckets)
                    if process_group is not None else None)
         self._comm: Optional[torch.cuda.Stream] = None
         self._force_dp = os.environ.get("STLPOSE_DP_FORCE", "0") == "1"   # exercise the DP path with one rank (tests)
@@ -49,7 +52,7 @@ class TrainStep:
         n = self.store.nparam
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev) if optimizer == ADAM else None
-        gscale = 1.0 / self.world
+        gscale = self.dp.grad_scale if self.dp is not None else 1.0   # 1/world, or 1 when the bf16 buckets carry the mean
         self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, momentum, float(nesterov), gscale],
                                   dtype=torch.float32, device=dev)
         self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)

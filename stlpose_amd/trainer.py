@@ -144,6 +144,25 @@ class Trainer:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
         return tuple((t / self.world).tolist())
 
+    def _common_steps(self, loader) -> Optional[int]:
+        """Steps per epoch every rank can take: the MINIMUM of the per-rank loader lengths.  Each step holds one
+        all-reduce per gradient bucket, so a rank that ran out of batches early would leave the others waiting in a
+        collective for ever (uneven shards: no drop_last, a last partial shard).  None with one process."""
+        if self.world == 1:
+            return None
+        import torch.distributed as dist
+        try:
+            n = len(loader)
+        except TypeError:
+            n = -1
+        t = torch.tensor([n, -n], dtype=torch.int64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+        lo = -int(t[1].item())
+        if lo < 0:
+            raise RuntimeError("Trainer with a process group: every rank's loader needs __len__ (a sharded sampler) so that the "
+                               "ranks can agree on the number of steps per epoch")
+        return lo
+
     def _barrier(self):
         if self.world > 1:
             import torch.distributed as dist
@@ -254,7 +273,10 @@ class Trainer:
     def train_epoch(self, epoch: int):
         self.model.train()
         losses, accs = [], []
+        steps = self._common_steps(self.train_loader)
         for i, (imgs, target, target_weight, meta) in enumerate(self.train_loader):
+            if steps is not None and i >= steps:
+                break
             self.ts.load_batch(imgs.float().to(self.device, non_blocking=True), target.float().to(self.device, non_blocking=True),
                                target_weight.float().to(self.device, non_blocking=True))
             # 02_train.py:208-212: loss = apply_perceptual_loss(exp_data, params, loss, metadata["perceptual_loss"]).

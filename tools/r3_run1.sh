@@ -22,3 +22,5 @@ bash tools/gpu_sweep.sh "X=0" \
 echo sweep done
 timeout -k 10 900 python -m pytest tests/test_parity_r3_gpu.py -x -q > $OUT/pytest_r3a.log 2>&1; echo "pytest rc $?"
 tail -5 $OUT/pytest_r3a.log
+timeout -k 10 600 python bench.py --steps 30 --warmup 8 > $OUT/bench_r3a.json 2> $OUT/bench_r3a.err; echo "bench rc $?"
+tail -c 600 $OUT/bench_r3a.err
