@@ -41,36 +41,46 @@ def synth_batch(B, H, W, rank, device, sigma=3.0, joints=17):
 
 
 def time_dominant_kernel(ts):
-    """The dominant kernel by GPU time (profiles/: ~25 % of the step) is the 3x3 stride-1 weight
-    gradient `wgrad_kernel<bf16,KS=3,GQ=1>` (BatchNorm-backward applied on load).  Every launch
-    of that instantiation in one backward pass is timed on its own with HIP events on the launch
-    stream; achieved = sum of algorithmic FLOPs / sum of durations."""
+    """The dominant kernel by GPU time is the 3x3 stride-1 weight gradient `wgrad_kernel<bf16,KS=3,GQ=1>` (BatchNorm
+    backward applied on load).  Since round 3 most of its launches are GROUPED (stl_conv_wgrad_group: up to four
+    weight gradients of one branch per launch).  Every launch of that instantiation in one backward pass -- grouped
+    or single -- is timed on its own with HIP events on the launch stream; achieved = algorithmic FLOPs (bytes) of all
+    members / sum of durations; the per-launch figures are averages over those launches."""
     from stlpose_amd import capi
     eng = ts.eng
-    ops = [d for n, d, *_ in eng.bwd_ops
-           if n == "stl_conv_wgrad" and d.ks == 3 and d.stride == 1 and d.g.mode == capi.SRC_BNBWD]
-    if not ops:
+
+    def dominant(d):
+        return d.ks == 3 and d.stride == 1 and d.g.mode == capi.SRC_BNBWD
+    launches = []   # (callable, member descriptors)
+    lib = capi.lib()
+    for n, d, *_ in eng.bwd_ops:
+        if n == "stl_conv_wgrad" and dominant(d):
+            launches.append((lambda st, d=d: lib.stl_conv_wgrad(C.byref(d), st), [d]))
+        elif n == "stl_conv_wgrad_group" and dominant(d.members[0]):
+            launches.append((lambda st, d=d: lib.stl_conv_wgrad_group(C.byref(d), st), list(d.members)))
+    if not launches:
         return None
     st = torch.cuda.current_stream().cuda_stream
-    lib = capi.lib()
-    for d in ops[:8]:
-        lib.stl_conv_wgrad(C.byref(d), st)
+    for fn, _ in launches[:8]:
+        fn(st)
     torch.cuda.synchronize()
     evs = []
-    for d in ops:
+    for fn, members in launches:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        lib.stl_conv_wgrad(C.byref(d), st)
+        fn(st)
         e1.record()
-        evs.append((e0, e1, d))
+        evs.append((e0, e1, members))
     torch.cuda.synchronize()
     tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
-    flops = sum(2.0 * d.B * d.Ho * d.Wo * d.Co * d.Ci * 9 for _, _, d in evs)
     esz = 2 if eng.dtype == capi.BF16 else 4
+    flops = sum(2.0 * d.B * d.Ho * d.Wo * d.Co * d.Ci * 9 for _, _, ms in evs for d in ms)
     # SURVEY 8(d): h, dt and y read once, dw written once (split-K slabs are NOT algorithmic bytes)
-    bytes_alg = sum((d.B * d.Hi * d.Wi * d.Ci + 2 * d.B * d.Ho * d.Wo * d.Co) * esz + d.Co * d.Ci * 9 * 4 for _, _, d in evs)
-    return dict(kernel="wgrad_kernel<bf16,KS=3,GQ=1,TPX=128|256> (3x3 stride-1 weight gradient, BN-backward on load)",
-                launches=len(evs), ms=tot_ms / len(evs), tflops=flops / tot_ms / 1e9, gbs=bytes_alg / tot_ms / 1e6)
+    bytes_alg = sum((d.B * d.Hi * d.Wi * d.Ci + 2 * d.B * d.Ho * d.Wo * d.Co) * esz + d.Co * d.Ci * 9 * 4 for _, _, ms in evs for d in ms)
+    nconv = sum(len(ms) for _, _, ms in evs)
+    return dict(kernel="wgrad_kernel<bf16,KS=3,GQ=1,TPX=128> (3x3 stride-1 weight gradient, BN-backward on load; grouped launches of up to "
+                       f"{max(len(ms) for _, _, ms in evs)} layers of one branch)",
+                launches=len(evs), convs=nconv, ms=tot_ms / len(evs), tflops=flops / tot_ms / 1e9, gbs=bytes_alg / tot_ms / 1e6)
 
 
 def cpu_baseline(arch, H, W, batch=32, steps=3, adam=True):
@@ -466,13 +476,14 @@ def main():
                 try:
                     rec = json.load(open(f))
                     if rec.get("launches") == dom["launches"] and (a.arch, a.height, a.width, a.batch, a.dtype) == ("w32", 384, 288, 32, "bf16") \
-                            and rec.get("fused_bwd", "0") == os.environ.get("STLPOSE_FUSED_BWD", "0"):
+                            and rec.get("fused_bwd", "0") == os.environ.get("STLPOSE_FUSED_BWD", "0") \
+                            and rec.get("wgrad_group", "1") == os.environ.get("STLPOSE_WGRAD_GROUP", "4"):
                         traffic, traffic_src = round(rec["traffic_bytes_per_launch"]), "profiles/" + os.path.basename(f)
                 except Exception:
                     pass
             roof = dict(bound="mfma", achieved=round(dom["tflops"], 2), peak=MFMA_PEAK_BF16, unit="TFLOP/s",
                         frac=round(dom["tflops"] / MFMA_PEAK_BF16, 4), traffic=traffic, kernel=dom["kernel"],
-                        launches_per_step=dom["launches"], avg_launch_us=round(dom["ms"] * 1e3, 2),
+                        launches_per_step=dom["launches"], layers_per_step=dom["convs"], avg_launch_us=round(dom["ms"] * 1e3, 2),
                         algorithmic_GBps=round(dom["gbs"], 1), hbm_frac=round(dom["gbs"] / HBM_PEAK, 4),
                         algorithmic_bytes_per_launch=round(dom["gbs"] * dom["ms"] * 1e6),
                         traffic_unit="HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)",

@@ -87,6 +87,8 @@ typedef struct stl_conv {
     stl_src wg_h;          /* the conv's forward input (PLAIN or BN source), [B,Ho,Wo,C]     */
     float* wg_partial;     /* [wg_nsplit][C][9][C] or NULL                                  */
     int32_t wg_nsplit;
+    int32_t grid_pct;      /* 0 / 100: default persistent-grid size; else per cent of it (the planner shrinks the grids of
+                              launches that run beside other branches' launches: they share the CUs instead of queueing) */
 } stl_conv;
 int stl_conv_forward(const stl_conv* p, void* stream);
 /* Fill p->shape / p->TH / p->TW once (host-side tile search) so that launches are cheap. */
@@ -108,6 +110,14 @@ typedef struct stl_wgrad {
     float* partial; /* [nsplit][Co][ks*ks][Ci] */
 } stl_wgrad;
 int stl_conv_wgrad(const stl_wgrad* p, void* stream);
+/* Up to STL_WGRAD_GROUP_MAX weight gradients of IDENTICAL geometry, tile, nsplit and gradient-source mode in one
+ * launch (grid.x = n * nsplit).  Same results as n stl_conv_wgrad calls; replaces n of the per-layer
+ * aten::convolution_backward weight parts of one branch (HRnet.py:140-186: the 3x3 convolutions of
+ * _make_one_branch share one shape). */
+#define STL_WGRAD_GROUP_MAX 8
+typedef struct stl_wgrad_io { stl_src h; stl_src g; float* partial; } stl_wgrad_io;
+typedef struct stl_wgrad_group { int32_t n, pad_; const stl_wgrad* p[STL_WGRAD_GROUP_MAX]; } stl_wgrad_group;
+int stl_conv_wgrad_group(const stl_wgrad_group* g, void* stream);
 /* Channel tile (32 or 64) of the kernel variant stl_conv_wgrad uses for this problem: the grid is
  * nsplit x ceil(Co/tile) x ceil(Ci/tile) blocks, which is what a caller sizes nsplit against. */
 int stl_wgrad_chunk(const stl_wgrad* p);
@@ -280,6 +290,7 @@ int stl_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H,
 #define STL_OP_HEAD_BWD 7
 #define STL_OP_REDUCE_RANGE 8 /* stl_reduce_slabs over a sub-range of the table (a gradient bucket) */
 #define STL_OP_BN_GRADS_RANGE 9 /* stl_bn_param_grads over a sub-range of the table */
+#define STL_OP_WGRAD_GROUP 10   /* stl_conv_wgrad_group */
 /* A gradient bucket = a contiguous slice of the flat gradient buffer whose weight-gradient slabs and
  * BatchNorm reductions are complete at some point of the backward program.  Reducing it there (and
  * recording an event) lets the data-parallel all-reduce of that slice start while the rest of

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("STLPOSE_HIP_LIB") or os.path.join(_HERE, "libstlpose_
 
 F32, BF16 = 0, 1
 NSHARD = 2
+WGRAD_GROUP_MAX = 8
 SRC_PLAIN, SRC_BN, SRC_BNBWD = 0, 1, 2
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -27,13 +28,17 @@ class Conv(C.Structure):
                 ("Co", i32), ("ks", i32), ("stride", i32), ("stuff", i32), ("TH", i32), ("TW", i32), ("shape", i32),
                 ("src", Src), ("w", vp), ("out", vp), ("bias", vp), ("out_relu", i32), ("out_stats", vp),
                 ("addend", vp), ("mask_y", vp), ("mask_bn", Src), ("red", vp), ("mask_z", vp),
-                ("wg_h", Src), ("partial", vp), ("wg_nsplit", i32)]   # `partial` = wg_partial (fused weight gradient slabs)
+                ("wg_h", Src), ("partial", vp), ("wg_nsplit", i32), ("grid_pct", i32)]   # `partial` = wg_partial (fused weight gradient slabs)
 
 
 class Wgrad(C.Structure):
     _fields_ = [("dtype", i32), ("B", i32), ("Hi", i32), ("Wi", i32), ("Ci", i32), ("Ho", i32), ("Wo", i32),
                 ("Co", i32), ("ks", i32), ("stride", i32), ("TH", i32), ("TW", i32), ("nsplit", i32),
                 ("h", Src), ("g", Src), ("partial", vp)]
+
+
+class WgradGroup(C.Structure):
+    _fields_ = [("n", i32), ("pad_", i32), ("p", C.POINTER(Wgrad) * 8)]
 
 
 class Term(C.Structure):
@@ -98,7 +103,7 @@ class BNRange(C.Structure):
 
 OP_KIND = {"stl_conv_forward": 0, "stl_conv_wgrad": 1, "stl_fuse_forward": 2, "stl_fuse_backward": 3,
            "stl_upsample_backward": 4, "stl_patch3x3": 5, "stl_head_forward": 6, "stl_head_backward": 7,
-           "stl_reduce_slabs_range": 8, "stl_bn_grads_range": 9}
+           "stl_reduce_slabs_range": 8, "stl_bn_grads_range": 9, "stl_conv_wgrad_group": 10}
 
 # name -> argtypes (restype is always int unless noted); every symbol include/stlpose_hip.h declares
 SIGNATURES = {
@@ -109,6 +114,7 @@ SIGNATURES = {
     "stl_debug_wgrad_stamps": [vp],
     "stl_conv_wgrad": [C.POINTER(Wgrad), vp],
     "stl_wgrad_chunk": [C.POINTER(Wgrad)],
+    "stl_conv_wgrad_group": [C.POINTER(WgradGroup), vp],
     "stl_fuse_forward": [C.POINTER(Fuse), vp],
     "stl_fuse_backward": [C.POINTER(FuseBwd), vp],
     "stl_upsample_backward": [C.POINTER(UpBwd), vp],

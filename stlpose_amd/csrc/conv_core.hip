@@ -896,6 +896,7 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     if (plan.shape == 8) cap = getenv("STL_CONV_GRID_CAP_S8") ? atoi(getenv("STL_CONV_GRID_CAP_S8")) : cap4 / 2;   // two 8-wave blocks per CU
     if (!getenv("STL_CONV_CAP_PER_TILE")) cap = std::max(8, (cap / k.ny + 7) / 8 * 8);
     if (const char* e = getenv("STL_CONV_GRID_CAP")) cap = atoi(e) > 0 ? (atoi(e) + 7) / 8 * 8 : cap;
+    if (p.grid_pct > 0 && p.grid_pct != 100) cap = std::max(8, (cap * p.grid_pct / 100 + 7) / 8 * 8);
     if (gx > cap) gx = cap;
     dim3 grid(gx * k.ny, 1);
     const int nva = ceil_div(k.HP * 4, sh.lthr);

@@ -85,6 +85,7 @@ extern "C" int stl_program_run(void* h, void* const* streams) {
         switch (o.kind) {
             case STL_OP_CONV: rc = stl_conv_forward(static_cast<const stl_conv*>(o.desc), st); break;
             case STL_OP_WGRAD: rc = stl_conv_wgrad(static_cast<const stl_wgrad*>(o.desc), st); break;
+            case STL_OP_WGRAD_GROUP: rc = stl_conv_wgrad_group(static_cast<const stl_wgrad_group*>(o.desc), st); break;
             case STL_OP_FUSE: rc = stl_fuse_forward(static_cast<const stl_fuse*>(o.desc), st); break;
             case STL_OP_FUSE_BWD: rc = stl_fuse_backward(static_cast<const stl_fuse_bwd*>(o.desc), st); break;
             case STL_OP_UP_BWD: rc = stl_upsample_backward(static_cast<const stl_upbwd*>(o.desc), st); break;

@@ -26,8 +26,11 @@ __device__ long long g_wstamps[16];
 #define WSTAMP(i) do {} while (0)
 #endif
 
+constexpr int WG_MAXG = STL_WGRAD_GROUP_MAX;
 struct WgK {
-    stl_wgrad p;
+    stl_wgrad p;           // problem 0 (geometry, tile, nsplit: shared by every member of a group)
+    stl_wgrad_io io[WG_MAXG];   // per member: sources and slab pointer (io[0] mirrors p)
+    int ng;                // members of this launch (1 = plain launch); grid.x = ng * p.nsplit
     int dbg;
     int tiles_c, npt, HR, HC, HP, PI, pad, taps;
     int psg, psh;  // LDS bytes per pixel (32 channels + 16 B pad)
@@ -113,6 +116,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
                                                   // K-step offsets of the fragment reads are instruction immediates
     constexpr int NKT = TPX / KSTEP;            // K steps per tile
     const stl_wgrad& p = k.p;
+    // grouped launch: blockIdx.x = member * nsplit + split.  The member's tensors come from k.io[member] (a uniform,
+    // run-time index into the kernel arguments: scalar loads), everything geometric from k.p.
+    const int member = blockIdx.x / p.nsplit, bsplit = blockIdx.x - member * p.nsplit;
+    const stl_wgrad_io& io = k.io[member];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
     const int mt = (wave & 3) >> 1, nt = wave & 1, tg = wave >> 2;
     const int co0 = blockIdx.y * 32, ci0 = blockIdx.z * 32;
@@ -190,8 +197,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
             }
             const size_t off = go >= 0 ? (size_t)go : 0;
             ok |= go >= 0 ? 1u << i : 0u;
-            rgv[S][i] = ldg16((const char*)p.g.x + off * sizeof(T));
-            if (GQ) rgq[S][i] = ldg16((const char*)p.g.y + off * sizeof(T));
+            rgv[S][i] = ldg16((const char*)io.g.x + off * sizeof(T));
+            if (GQ) rgq[S][i] = ldg16((const char*)io.g.y + off * sizeof(T));
         }
         const int vrs = vr0 * p.stride, cb = c0 * p.stride - k.pad;
         const int hb0 = fdiv(vrs, k.r_PI), hy0 = vrs - hb0 * k.PI - k.pad;
@@ -208,11 +215,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
             }
             const size_t off = ho >= 0 ? (size_t)ho : 0;
             ok |= ho >= 0 ? 1u << (NVG + i) : 0u;
-            rhv[S][i] = ldg16((const char*)p.h.x + off * sizeof(T));
+            rhv[S][i] = ldg16((const char*)io.h.x + off * sizeof(T));
         }
         okm[S] = ok;
     };
-    const float relu_lo = p.h.relu ? 0.f : -INFINITY;
+    const float relu_lo = io.h.relu ? 0.f : -INFINITY;
     auto write_lds = [&](auto SET) __attribute__((always_inline)) {
         constexpr int S = decltype(SET)::value;
         const int cl = g_part * KV;
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
         for (int i = 0; i < NVH; ++i) {
             if (h_rc[i] < 0) continue;
             V16 val = rhv[S][i];
-            if (p.h.mode == STL_SRC_BN) val = xform_bn<T>(val, chc + cl, chc + 32 + cl, relu_lo);
+            if (io.h.mode == STL_SRC_BN) val = xform_bn<T>(val, chc + cl, chc + 32 + cl, relu_lo);
             mask16(val, (okm[S] >> (NVG + i)) & 1u);
             const int v = tid + i * NT;
             *reinterpret_cast<V16*>(sH + (v / VPX) * PS + g_part * 16) = val;
@@ -284,8 +291,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
         }
     };
 
-    const int step = gridDim.x;
-    int t = blockIdx.x;
+    const int step = p.nsplit;
+    int t = bsplit;
     WSTAMP(1);
     // BatchNorm constants (wave 3: lanes 0-31 those of g, 32-63 those of h): the statistics loads are issued ahead
     // of the first tiles' loads, the arithmetic runs while those are in flight
@@ -294,8 +301,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
     const int cch = lane & 31;
     const bool cok = cw && (cg ? co0 + cch < p.Co : ci0 + cch < p.Ci);
     if (cok) {
-        if (cg) src_raw_load(p.g, co0 + cch, p.Co, raw);
-        else src_raw_load(p.h, ci0 + cch, p.Ci, raw);
+        if (cg) src_raw_load(io.g, co0 + cch, p.Co, raw);
+        else src_raw_load(io.h, ci0 + cch, p.Ci, raw);
     }
     constexpr std::integral_constant<int, 0> I0{};
     constexpr std::integral_constant<int, 1> I1{};
@@ -305,8 +312,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
     if (cw) {
         float a = 0.f, b = 0.f, cc = 0.f;
         if (cok) {
-            if (cg) src_raw_finish(p.g, raw, a, b, cc);
-            else src_raw_finish(p.h, raw, a, b, cc);
+            if (cg) src_raw_finish(io.g, raw, a, b, cc);
+            else src_raw_finish(io.h, raw, a, b, cc);
         }
         if (cg) cgc[cch] = a, cgc[32 + cch] = b, cgc[64 + cch] = cc;
         else chc[cch] = a, chc[32 + cch] = b;
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
     }
     WSTAMP(6);
     {   // every wave writes its quadrant (and its taps) of the block's slab [Co][taps][Ci]
-        float* slab = p.partial + (size_t)blockIdx.x * p.Co * TAPS * p.Ci;
+        float* slab = io.partial + (size_t)bsplit * p.Co * TAPS * p.Ci;
         const int ci = ci0 + nt * 16 + (lane & 15), co = co0 + mt * 16 + 4 * g;
         const int tap0 = tg * TPG;
         float* dst = slab + ((size_t)co * TAPS + tap0) * p.Ci + ci;
@@ -667,8 +674,33 @@ extern "C" int stl_debug_wgrad_stamps(long long* host16) {
 
 extern "C" int stl_wgrad_chunk(const stl_wgrad* pp) { return wgrad_chunk(*pp); }
 
-extern "C" int stl_conv_wgrad(const stl_wgrad* pp, void* stream) {
-    const stl_wgrad& p = *pp;
+static int wgrad_run(const stl_wgrad* const* ps, int ng, void* stream);
+
+extern "C" int stl_conv_wgrad(const stl_wgrad* pp, void* stream) { return wgrad_run(&pp, 1, stream); }
+
+// Several weight gradients of identical geometry (same layer shape, tile, split count and source modes -- e.g. the
+// eight 3x3 convolutions of one branch of an exchange module) in ONE launch: grid.x = n * nsplit, block
+// (member, split) works on member's tensors.  One launch instead of n keeps the hardware queues free for the
+// data-gradient chain, and with the block budget shared by the members every block walks n times as many pixel
+// tiles (longer steady state, n times fewer split-K slabs to write and to reduce).
+extern "C" int stl_conv_wgrad_group(const stl_wgrad_group* grp, void* stream) {
+    STL_CHECK(grp && grp->n >= 1 && grp->n <= WG_MAXG, "wgrad_group: 1..%d members", WG_MAXG);
+    const stl_wgrad& a = *grp->p[0];
+    for (int i = 1; i < grp->n; ++i) {
+        const stl_wgrad& b = *grp->p[i];
+        STL_CHECK(b.dtype == a.dtype && b.B == a.B && b.Hi == a.Hi && b.Wi == a.Wi && b.Ci == a.Ci && b.Ho == a.Ho && b.Wo == a.Wo &&
+                      b.Co == a.Co && b.ks == a.ks && b.stride == a.stride && b.TH == a.TH && b.TW == a.TW && b.nsplit == a.nsplit &&
+                      b.g.mode == a.g.mode,
+                  "wgrad_group: member %d differs from member 0 in geometry, tile, nsplit or gradient source mode", i);
+    }
+    STL_CHECK(grp->n == 1 || wgrad_chunk(a) == 32, "wgrad_group: the 64 x 64-channel variant is not grouped");
+    return wgrad_run(grp->p, grp->n, stream);
+}
+
+static int wgrad_run(const stl_wgrad* const* ps, int ng, void* stream) {
+    const stl_wgrad& p = *ps[0];
+  for (int i_ = 0; i_ < ng; ++i_) {
+    const stl_wgrad& p = *ps[i_];
     STL_CHECK(p.dtype == STL_F32 || p.dtype == STL_BF16, "wgrad: bad dtype");
     STL_CHECK(p.ks == 1 || p.ks == 3, "wgrad: ks must be 1 or 3");
     STL_CHECK(p.stride == 1 || p.stride == 2, "wgrad: stride must be 1 or 2");
@@ -685,8 +717,12 @@ extern "C" int stl_conv_wgrad(const stl_wgrad* pp, void* stream) {
     STL_CHECK(p.g.mode == STL_SRC_PLAIN || p.g.mode == STL_SRC_BNBWD, "wgrad: g must be PLAIN or BNBWD");
     STL_CHECK(p.g.mode != STL_SRC_BNBWD || (p.g.y && p.g.stats && p.g.rstats && p.g.gamma), "wgrad: BNBWD source incomplete");
     STL_CHECK(p.h.mode != STL_SRC_BN || (p.h.gamma && p.h.beta && (p.h.stats || (p.h.rmean && p.h.rvar))), "wgrad: BN source incomplete");
+  }
+    const int pad = p.ks == 3 ? 1 : 0;
     WgK k;
     k.p = p;
+    k.ng = ng;
+    for (int i = 0; i < ng; ++i) k.io[i].h = ps[i]->h, k.io[i].g = ps[i]->g, k.io[i].partial = ps[i]->partial;
     k.dbg = getenv("STL_CONV_STAMPS") ? 1 : 0;
     k.taps = p.ks * p.ks;
     k.pad = pad;
@@ -706,7 +742,7 @@ extern "C" int stl_conv_wgrad(const stl_wgrad* pp, void* stream) {
         const size_t lds64 = (size_t)k.off_h + (size_t)k.HP * k.psh;
         STL_CHECK(lds64 <= 160 * 1024, "wgrad64: tile needs %zu B of LDS (>160 KiB)", lds64);
         STL_CHECK(p.nsplit <= k.npt || p.nsplit == 1, "wgrad: nsplit %d > tiles %d", p.nsplit, k.npt);
-        dim3 grid64(p.nsplit, ceil_div(p.Co, 64), ceil_div(p.Ci, 64));
+        dim3 grid64(p.nsplit, ceil_div(p.Co, 64), ceil_div(p.Ci, 64));   // never grouped (ng == 1)
         return p.ks == 3 ? dispatch64<3>(k, grid64, lds64, st) : dispatch64<1>(k, grid64, lds64, st);
     }
     const int esz = p.dtype == STL_BF16 ? 2 : 4;
@@ -720,7 +756,7 @@ extern "C" int stl_conv_wgrad(const stl_wgrad* pp, void* stream) {
     size_t lds = (size_t)k.off_h + szH;
     STL_CHECK(lds <= 160 * 1024, "wgrad: tile needs %zu B of LDS (>160 KiB)", lds);
     STL_CHECK(p.nsplit <= k.npt || p.nsplit == 1, "wgrad: nsplit %d > tiles %d", p.nsplit, k.npt);
-    dim3 grid(p.nsplit, ceil_div(p.Co, 32), ceil_div(p.Ci, 32));
+    dim3 grid(p.nsplit * ng, ceil_div(p.Co, 32), ceil_div(p.Ci, 32));
     if (p.dtype == STL_BF16) return p.ks == 3 ? dispatch<__bf16, 3>(k, grid, lds, st) : dispatch<__bf16, 1>(k, grid, lds, st);
     return p.ks == 3 ? dispatch<float, 3>(k, grid, lds, st) : dispatch<float, 1>(k, grid, lds, st);
 }

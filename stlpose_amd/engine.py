@@ -272,6 +272,7 @@ class Engine:
         p.ks, p.stride, p.stuff = kks, kstride, 0
         p.TH, p.TW, p.shape = 0, 0, -1
         capi.call("stl_conv_plan", C.byref(p))  # block shape + pixel tile, searched once
+        p.grid_pct = self._grid_pct(ck)
         p.src = self._src(x)
         p.out = y.ptr
         if self.training:
@@ -334,6 +335,23 @@ class Engine:
         self._wprep_n = len(self.convs)
         self.weights_ready = False   # set by a caller that has already run prep_weights_range for every bucket
 
+    def _active_of(self, key: str) -> int:
+        """Branch chains in flight around the layer `key` (its stage's branch count)."""
+        if key.startswith("stage"):
+            return int(key[5])
+        if key.startswith("transition") and key[10] in "23":
+            return int(key[10])
+        return 1 if not key.startswith("final") else self.nstreams
+
+    def _grid_pct(self, key: str) -> int:
+        """STLPOSE_CAP_SCALE='p1,p2,p3,p4': persistent-grid size (per cent of the kernel's default) of a launch that
+        runs beside 0 / 1 / 2 / 3 other branch chains."""
+        spec = os.environ.get("STLPOSE_CAP_SCALE", "")
+        if not spec:
+            return 0
+        pcts = [int(v) for v in spec.split(",")]
+        return pcts[min(self._active_of(key), self.nstreams, len(pcts)) - 1]
+
     # ------------------------------------------------------------------ backward program
     def _new_grad(self, a: Act) -> torch.Tensor:
         return self._act_tensor(a.B, a.H, a.W, a.C)
@@ -370,12 +388,16 @@ class Engine:
             bk["done"] += size
             bk["lo"] = min(bk["lo"], off)
 
+        self._wg_pending: Dict[Tuple, List] = {}   # grouped weight gradients waiting for their group to fill
+
         def bucket_close(force: bool = False):
             complete = bk["done"] == bk["hi"] - bk["lo"]          # suffix [lo, hi) fully covered
             force = force or (complete and bk["lo"] in force_at)
             if not complete or bk["done"] == 0 or (bk["done"] < bucket_min and not force):
                 return
             assert complete
+            for key in list(self._wg_pending):                     # the bucket's slab reduction reads every member's slabs
+                self._flush_wgrad_group(ops, key)
             rr, br = capi.ReduceRange(), capi.BNRange()
             b = dict(lo=bk["lo"], hi=bk["hi"], slab0=bk["slab0"], slab1=len(self.slabs), rr=rr, br=br)
             wstrm = bk["strm"]
@@ -387,12 +409,7 @@ class Engine:
         self._nactive: Dict[int, int] = {}   # id(desc) -> branch streams busy with the data-gradient chain around that op
         cur_active = self.nstreams
 
-        def active_of(key: str) -> int:
-            if key.startswith("stage"):
-                return int(key[5])
-            if key.startswith("transition") and key[10] in "23":
-                return int(key[10])
-            return 1 if not key.startswith("final") else self.nstreams
+        active_of = self._active_of
         n_before = 0
         for node in reversed(self.tape):
             kind = node[0]
@@ -492,6 +509,7 @@ class Engine:
                 if fuse_wg:
                     d.partial = 1   # plan for the fused block shape; the slab pointer is patched in below
                 capi.call("stl_conv_plan", C.byref(d))
+                d.grid_pct = self._grid_pct(ci.key)
                 d.src = g
                 d.w = self.wk.data_ptr() + ci.bwd_off * self.esz
                 dreads = [y.dt.data_ptr()]
@@ -593,6 +611,10 @@ class Engine:
         if name == "stl_conv_wgrad":
             by = (d.B * d.Hi * d.Wi * d.Ci + d.B * d.Ho * d.Wo * d.Co * (2 if d.g.mode == capi.SRC_BNBWD else 1)) * esz
             return 16.0 + (by + 2.0 * d.nsplit * d.Co * d.Ci * d.ks * d.ks * 4) / 2.0e6
+        if name == "stl_conv_wgrad_group":
+            m = d.members[0]
+            by = (m.B * m.Hi * m.Wi * m.Ci + m.B * m.Ho * m.Wo * m.Co * (2 if m.g.mode == capi.SRC_BNBWD else 1)) * esz
+            return 16.0 + d.n * (by + 2.0 * m.nsplit * m.Co * m.Ci * m.ks * m.ks * 4) / 2.0e6
         if name == "stl_fuse_backward":
             return 8.0 + d.B * d.H * d.W * d.C * (d.ngrads + 2 + d.nbn) * esz / 3.0e6
         if name == "stl_upsample_backward":
@@ -619,7 +641,7 @@ class Engine:
         for op in ops:
             name, desc, strm, reads, writes = op
             cost = self._op_cost_us(op)
-            if name in ("stl_conv_wgrad", "stl_reduce_slabs_range", "stl_bn_grads_range"):
+            if name in ("stl_conv_wgrad", "stl_conv_wgrad_group", "stl_reduce_slabs_range", "stl_bn_grads_range"):
                 active = self._nactive.get(id(desc), self.nstreams)
                 own = strm % self.nstreams
                 if os.environ.get("STLPOSE_BALANCE", "idle") == "idle":
@@ -707,15 +729,51 @@ class Engine:
         wg.nsplit = min(range(1, top + 1), key=lambda ns: (math.ceil(npt / ns) + 0.004 * ns * chunks / 8, ns))
         wg.h = self._src(x)
         wg.g = g
+        # Grouped launches (stl_conv_wgrad_group): weight gradients of one shape -- the 3x3 convolutions of a branch --
+        # wait until `gsize` of them are ready and go out as ONE launch that shares the block budget: the four hardware
+        # queues carry one off-chain launch instead of gsize (in stages 3 / 4 every queue is busy with a data-gradient
+        # chain and each stand-alone weight gradient costs its chain a full launch latency, whatever its size), every
+        # block walks gsize times as many pixel tiles, and gsize times fewer split-K slabs are written and reduced.
+        gsize = 1
+        if ctile == 32 and not big and os.environ.get("STLPOSE_SKIP_WGRAD", "0") == "0":
+            gsize = max(1, min(int(os.environ.get("STLPOSE_WGRAD_GROUP", "4")), capi.WGRAD_GROUP_MAX, max(1, budget // chunks)))
+        if gsize > 1:
+            bg = budget // gsize
+            top = max(1, min(npt, bg // chunks if chunks <= bg else 1))
+            wg.nsplit = min(range(1, top + 1), key=lambda ns: (math.ceil(npt / ns) + 0.004 * ns * chunks / 8, ns))
         nel = y.C * kks * kks * x.C
         part_off = self._slab_elems
         self._slab_elems += (wg.nsplit * nel + 3) // 4 * 4
         self.slabs.append(dict(part_off=part_off, grad_off=ci.master_off, nsplit=wg.nsplit, Co=ci.Co, Ci=ci.Ci,
                                ks=ci.ks, Cip=ci.Cik, patch=int(ci.patch), stride=0, struct=wg))
-        if os.environ.get("STLPOSE_SKIP_WGRAD", "0") == "0":   # calibration only ("1": no weight-gradient launches, slabs stay zero)
-            ops.append(("stl_conv_wgrad", wg, wstrm, [y.dt.data_ptr(), x.ptr], [id(wg)]))
         bk["reads"].append(id(wg))
         bk["strm"] = wstrm
+        if os.environ.get("STLPOSE_SKIP_WGRAD", "0") != "0":   # calibration only: no weight-gradient launches, slabs stay zero
+            return
+        if gsize == 1:
+            ops.append(("stl_conv_wgrad", wg, wstrm, [y.dt.data_ptr(), x.ptr], [id(wg)]))
+            return
+        key = (x.C, y.C, kks, kstride, x.H, x.W, wg.TH, wg.TW, wg.nsplit, int(g.mode), gsize)
+        pend = self._wg_pending.setdefault(key, [])
+        pend.append((wg, [y.dt.data_ptr(), x.ptr], wstrm))
+        if len(pend) >= gsize:
+            self._flush_wgrad_group(ops, key)
+
+    def _flush_wgrad_group(self, ops, key):
+        pend = self._wg_pending.pop(key, [])
+        if not pend:
+            return
+        if len(pend) == 1:
+            wg, reads, wstrm = pend[0]
+            ops.append(("stl_conv_wgrad", wg, wstrm, reads, [id(wg)]))
+            return
+        grp = capi.WgradGroup()
+        grp.n = len(pend)
+        for i, (wg, _r, _s) in enumerate(pend):
+            grp.p[i] = C.pointer(wg)
+        self._keep.append([wg for wg, _r, _s in pend])
+        grp.members = [wg for wg, _r, _s in pend]   # python-side view (bench, tools)
+        ops.append(("stl_conv_wgrad_group", grp, pend[-1][2], [r for _w, rs, _s in pend for r in rs], [id(wg) for wg, _r, _s in pend]))
 
     def _build_tables(self):
         tab = (capi.BNRec * len(self.bns))()
@@ -823,19 +881,26 @@ class Engine:
         self._side = []
         m_off = self._cu_range(os.environ.get("STLPOSE_CUMASK_OFF", ""))
         m_chain = self._cu_range(os.environ.get("STLPOSE_CUMASK_CHAIN", ""))
+        # ONE set of side streams per device, shared by every engine (engines never run concurrently): each new HIP
+        # stream is another hardware queue, queues are spread round-robin over the four compute pipes, and two ACTIVE
+        # queues on one pipe are time-sliced -- a second engine with streams of its own ran its plan at half speed
+        # (W32 256x192 as the second plan of a process: 20.8 ms per step instead of 10.2).
+        pool = _STREAM_POOL.setdefault((self.dev.index, os.environ.get("STLPOSE_CUMASK_OFF", ""), os.environ.get("STLPOSE_CUMASK_CHAIN", "")), {})
         with torch.cuda.device(self.dev):
             for i in range(1, n):
                 op_stream = i - off                     # index in the planner's numbering
                 mask = m_chain if op_stream < self.nstreams else m_off
-                if mask is not None:
-                    h = C.c_void_p()
-                    capi.call("stl_stream_create_masked", mask, 8, C.byref(h))
-                    self._side.append(h)                # lives as long as the engine
-                    self._stream_arr[i] = h.value
-                else:
-                    s_ = torch.cuda.Stream(device=self.dev)
-                    self._side.append(s_)
-                    self._stream_arr[i] = s_.cuda_stream
+                key = (i, mask is not None)
+                if key not in pool:
+                    if mask is not None:
+                        h = C.c_void_p()
+                        capi.call("stl_stream_create_masked", mask, 8, C.byref(h))
+                        pool[key] = (h, h.value)        # lives as long as the process
+                    else:
+                        s_ = torch.cuda.Stream(device=self.dev)
+                        pool[key] = (s_, s_.cuda_stream)
+                self._side.append(pool[key][0])
+                self._stream_arr[i] = pool[key][1]
 
     def prep_weights(self, stream: int):
         st = self.store
@@ -882,6 +947,9 @@ class Engine:
         """Make `stream` wait until gradient bucket i (self.buckets[i]: flat slice [lo, hi)) of the
         backward pass enqueued last is final."""
         capi.call("stl_program_wait_op", self._program(self.bwd_ops), self.buckets[i]["op"], stream)
+
+
+_STREAM_POOL: Dict[Tuple, Dict] = {}   # (device, mask specs) -> {(stream index, masked): (owner object, hipStream_t)}
 
 
 def _is_bn_weight(key: str, reg: Registry) -> bool:

@@ -82,12 +82,24 @@ def test_planner_dry_run(monkeypatch):
     # 292 weight gradients: 132 of them (3x3 stride-1 C -> C with C = 32 / 64: 2 x 64 two-conv-unit convs + the 4
     # bottleneck 3x3s) ride inside their data-gradient launch (fused backward), 160 are stand-alone launches
     fused = sum(1 for o in e.bwd_ops if o[0] == "stl_conv_forward" and o[1].partial)
-    assert fused == 132 and b["stl_conv_wgrad"] == 292 - fused
+    def nwg(c):   # weight gradients launched stand-alone or as members of grouped launches (round 3)
+        return c["stl_conv_wgrad"] + sum(o[1].n for o in e_.bwd_ops if o[0] == "stl_conv_wgrad_group")
+    e_ = e
+    assert fused == 132 and nwg(b) == 292 - fused
     assert b["stl_conv_forward"] == 291 and b["stl_upsample_backward"] == 28
     assert len(e.slabs) == 292 + 2   # + head weight and bias
     monkeypatch.setenv("STLPOSE_FUSED_BWD", "0")
     e0 = Engine(m.arch, m._store, 2, 256, 192, capi.BF16, True)
-    assert Counter(o[0] for o in e0.bwd_ops)["stl_conv_wgrad"] == 292
+    e_ = e0
+    c0 = Counter(o[0] for o in e0.bwd_ops)
+    assert nwg(c0) == 292 and 0 < c0["stl_conv_wgrad_group"] < 80 and c0["stl_conv_wgrad"] < 80   # most layers ride in groups of up to 4
+    for o in e0.bwd_ops:
+        if o[0] == "stl_conv_wgrad_group":
+            ms = o[1].members
+            assert 2 <= o[1].n <= 4 and len({(m.Ci, m.Co, m.ks, m.stride, m.Hi, m.Wi, m.TH, m.TW, m.nsplit, m.g.mode) for m in ms}) == 1
+    monkeypatch.setenv("STLPOSE_WGRAD_GROUP", "1")
+    assert Counter(o[0] for o in Engine(m.arch, m._store, 2, 256, 192, capi.BF16, True).bwd_ops)["stl_conv_wgrad"] == 292
+    monkeypatch.delenv("STLPOSE_WGRAD_GROUP")
     assert len(e.bns) == 292 and e.out.shape == (2, 17, 64, 48)
     ev = Engine(m.arch, m._store, 1, 64, 64, capi.F32, False)
     assert not ev.bwd_ops

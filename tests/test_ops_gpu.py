@@ -549,3 +549,63 @@ def test_gaussian_targets_match_reference_golden(golden_dir):
         assert np.array_equal(tw.cpu().numpy(), g[f"{tag}_tw"])
         assert np.abs(tgt.cpu().numpy() - g[f"{tag}_target"]).max() < 2e-7
         assert np.array_equal(tgt.cpu().numpy() > 0, g[f"{tag}_target"] > 0)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 24, 16, 32, 32, 3, 1, 3), (3, 12, 9, 64, 64, 3, 1, 4), (2, 24, 18, 32, 64, 3, 2, 2), (2, 12, 9, 128, 32, 1, 1, 8)])
+def test_wgrad_group_equals_single_launches(case, dt):
+    """stl_conv_wgrad_group (several weight gradients of one shape in ONE launch, grid.x = n * nsplit) against n
+    stl_conv_wgrad launches on the same tensors: every block does the same work in the same order -> bit-identical
+    slabs.  Sources: BN (+ReLU) on h and BatchNorm-backward on g, like the layers the planner groups."""
+    B, H, W, Ci, Co, ks, s, n = case
+    code, td, _ = DT[dt]
+    pad = 1 if ks == 3 else 0
+    Ho, Wo = (H + 2 * pad - ks) // s + 1, (W + 2 * pad - ks) // s + 1
+    torch.manual_seed(5)
+    keep, members = [], []
+    TH, TW = choose_tile(B, Ho, Wo, s, ks, 2 if dt == "bf16" else 4, bn_cols=32, maxhalo=576)
+    npt = math.ceil(B * (Ho + 1) / TH) * math.ceil(Wo / TW)
+    nsplit = min(3, npt)
+    nel = Co * ks * ks * Ci
+    for i in range(n):
+        h = nhwc(torch.randn(B, Ci, H, W, device="cuda"), td)
+        y = nhwc(torch.randn(B, Co, Ho, Wo, device="cuda"), td)
+        dtt = nhwc(torch.randn(B, Co, Ho, Wo, device="cuda"), td)
+        g1, b1 = torch.rand(Ci, device="cuda") + 0.5, torch.randn(Ci, device="cuda") * 0.1
+        g2 = torch.rand(Co, device="cuda") + 0.5
+        st1, st2 = stats_of(h, Ci), stats_of(y, Co)
+        yf = y.float().reshape(-1, Co).double()
+        mean2, rstd2 = yf.mean(0), 1.0 / torch.sqrt(yf.var(0, unbiased=False) + EPS)
+        df = dtt.float().reshape(-1, Co).double()
+        rst2 = torch.zeros(capi.NSHARD, 2, Co, dtype=torch.float64, device="cuda")
+        rst2[0, 0], rst2[0, 1] = df.sum(0), (df * (yf - mean2) * rstd2).sum(0)
+        gs = capi.Src()
+        gs.x, gs.y, gs.mode = dtt.data_ptr(), y.data_ptr(), capi.SRC_BNBWD
+        gs.stats, gs.rstats, gs.gamma = st2.data_ptr(), rst2.data_ptr(), g2.data_ptr()
+        gs.inv_count, gs.eps = 1.0 / (B * Ho * Wo), EPS
+        wg = capi.Wgrad()
+        wg.dtype, wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = code, B, H, W, Ci, Ho, Wo, Co
+        wg.ks, wg.stride, wg.TH, wg.TW, wg.nsplit = ks, s, TH, TW, nsplit
+        wg.h = bn_src(h, st1, g1, b1, B * H * W, relu=(i % 2 == 0)) if i != 1 else capi.Src()
+        if i == 1:   # one member with a PLAIN forward input (block-end sums are plain tensors)
+            wg.h.x, wg.h.mode = h.data_ptr(), capi.SRC_PLAIN
+        wg.g = gs
+        single = torch.full((nsplit * nel,), float("nan"), device="cuda")
+        grouped = torch.full((nsplit * nel,), float("nan"), device="cuda")
+        wg.partial = single.data_ptr()
+        capi.call("stl_conv_wgrad", C.byref(wg), stream())
+        torch.cuda.synchronize()
+        wg.partial = grouped.data_ptr()
+        keep.append((h, y, dtt, g1, b1, g2, st1, st2, rst2))
+        members.append((wg, single, grouped))
+    grp = capi.WgradGroup()
+    grp.n = n
+    for i, (wg, _s, _g) in enumerate(members):
+        grp.p[i] = C.pointer(wg)
+    capi.call("stl_conv_wgrad_group", C.byref(grp), stream())
+    torch.cuda.synchronize()
+    for i, (_wg, single, grouped) in enumerate(members):
+        assert not torch.isnan(single).any() and torch.equal(single, grouped), f"member {i} differs from its stand-alone launch"
+    # a member of another shape is refused
+    members[-1][0].Co += 8
+    assert capi.lib().stl_conv_wgrad_group(C.byref(grp), stream()) != 0

@@ -39,27 +39,52 @@ def _load_synth(model):
 
 
 # ------------------------------------------------------------------------------------------------ bf16 on peaky heat maps
+def textured_batch(b, h, w, joints=17, seed=4321, sigma=3.0):
+    """A batch a network CAN localise on (pure-noise images -- SURVEY 8(d)'s throughput input -- cannot be fitted in a
+    few hundred steps: 1500 Adam steps reached PCK 0.27): weak noise plus, at every joint, an oriented Gabor patch whose
+    orientation / frequency / colour identify the joint.  Targets as in JointsDataset.py:248-281 (unnormalised gaussian)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    hh, ww = h // 4, w // 4
+    ys, xs = np.mgrid[0:hh, 0:ww].astype(np.float32)
+    Y, X = np.mgrid[0:h, 0:w].astype(np.float32)
+    tgt = np.zeros((b, joints, hh, ww), np.float32)
+    img = 0.3 * rng.standard_normal((b, 3, h, w)).astype(np.float32)
+    ang = np.pi * np.arange(joints) / joints
+    freq = 0.35 + 0.25 * (np.arange(joints) % 3)
+    col = rng.standard_normal((joints, 3)).astype(np.float32)
+    for n in range(b):
+        for j in range(joints):
+            cx, cy = rng.integers(3, ww - 3), rng.integers(3, hh - 3)
+            tgt[n, j] = np.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) / (2 * sigma ** 2))
+            env = np.exp(-((X - 4 * cx - 1.5) ** 2 + (Y - 4 * cy - 1.5) ** 2) / (2 * 7.0 ** 2))
+            ph = freq[j] * (np.cos(ang[j]) * X + np.sin(ang[j]) * Y)
+            img[n, 0] += 2 * env * np.cos(ph)
+            img[n, 1] += 2 * env * np.sin(ph)
+            img[n] += env[None] * col[j][:, None, None]
+    return img, tgt, np.ones((b, joints, 1), np.float32)
+
+
 @pytest.fixture(scope="module")
 def trained_b32():
-    """Fit W32 to ONE synthetic batch (32 x 3 x 384 x 288, sigma 3) with the fp32 TrainStep until the device PCK on
-    that batch exceeds 0.85 (at most 1500 Adam steps), and hand back the weights + the oracle's forward at them."""
+    """Fit W32 to ONE textured batch (32 x 3 x 384 x 288, sigma 3) with the fused TrainStep (bf16 path: only the
+    resulting WEIGHTS matter here) until the device PCK on that batch exceeds 0.9 (at most 4000 Adam steps), and hand
+    back the weights + the fp32 oracle's forward at them."""
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    img, tgt, tw = synth_batch(32, 384, 288, seed=4321, sigma=3.0)
-    tw[:] = 1.0   # every joint supervised: PCK counts all 544 maps
-    m = _load_synth(PoseHighResolutionNet("w32", "fp32"))
+    img, tgt, tw = textured_batch(32, 384, 288)
+    m = _load_synth(PoseHighResolutionNet("w32", "bf16"))
     ts = TrainStep(m, 32, 384, 288, optimizer="adam", lr=1e-3)
     ti, tt, tww = torch.from_numpy(img).cuda(), torch.from_numpy(tgt).cuda(), torch.from_numpy(tw).cuda()
     ts.load_batch(ti, tt, tww)
     hist, steps = [], 0
-    while steps < 1500:
-        for _ in range(50):
+    while steps < 4000:
+        for _ in range(100):
             loss = ts.step()
-        steps += 50
+        steps += 100
         m.train()
         with torch.no_grad():
             pck = accuracy(m(ti), tt)[1]
         hist.append((steps, float(loss.item()), float(pck)))
-        if pck > 0.85:
+        if pck > 0.9:
             break
     torch.cuda.synchronize()
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}

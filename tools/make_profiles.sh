@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): regenerates everything under profiles/ for round $1 (default r02).
 # rocprofv3 needs TMPDIR=/tmp and the program itself after "--"; --pmc passes are separate runs with --kernel-trace only.
-R=${1:-r02}
+R=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/profiles_$R
 mkdir -p $OUT
@@ -30,7 +30,8 @@ done
 NW=$(python -c "import json;print(json.load(open('$OUT/${R}_bench.json'))['roofline']['launches_per_step'])")
 python $ROOT/tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $NW $OUT/${R}_pmc_wgrad.json > /dev/null
 python $ROOT/tools/step_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${R}_step_traffic.txt
-python $ROOT/tools/mfma_util.py $OUT/pmc_mfma $OUT/${R}_mfma_util.json > $OUT/${R}_mfma_util.txt
+SERIAL_MS=$(grep -o "sum of kernel time [0-9.]*" $OUT/${R}_trace_serial_summary.txt | grep -o "[0-9.]*$")
+python $ROOT/tools/mfma_util.py $OUT/pmc_mfma $OUT/${R}_mfma_util.json $SERIAL_MS > $OUT/${R}_mfma_util.txt
 rm -rf $OUT/trace_default $OUT/trace_serial $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma
 ls -la $OUT
 echo profiles done

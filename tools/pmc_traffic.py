@@ -28,7 +28,7 @@ def main():
     res = dict(kernel="wgrad_kernel<bf16,KS=3,GQ=1> (3x3 stride-1, BN-backward on load)", launches=n,
                fetch_size_raw_kb_per_launch=sum(fetch_kb) / n, write_size_raw_kb_per_launch=sum(write_kb) / n,
                fetch_bytes_per_launch=fetch_b, write_bytes_per_launch=write_b, traffic_bytes_per_launch=fetch_b + write_b,
-               fused_bwd=os.environ.get("STLPOSE_FUSED_BWD", "0"),
+               fused_bwd=os.environ.get("STLPOSE_FUSED_BWD", "0"), wgrad_group=os.environ.get("STLPOSE_WGRAD_GROUP", "4"),
                note="FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE as is; separate --pmc passes")
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
