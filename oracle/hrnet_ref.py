@@ -219,7 +219,10 @@ def load_synth(model: nn.Module, seed: int = 0) -> nn.Module:
 # (the head excepted: fp32 weights, fp32 output) sees its input and its weight rounded to
 # bf16 and has its raw output rounded to bf16 before the BatchNorm reads it.  The distance of
 # that run from the plain fp32 oracle is what bf16 STORAGE costs on a given batch -- the HIP
-# path is held to a small multiple of it, not to a free constant.
+# path is held to a small multiple of it, not to a free constant.  The materialised sums
+# (residual block ends, exchange sums, transition outputs) are rounded too: they are stored in
+# bf16 by the HIP path and travel on along the skip connections, i.e. the residual stream
+# itself carries 2^-9 of relative rounding per block.
 # ----------------------------------------------------------------------------------------
 class bf16_storage:
     def __init__(self, model: nn.Module):
@@ -239,6 +242,13 @@ class bf16_storage:
                 self.saved[name] = m.weight.data
                 m.weight.data = self._r(m.weight.data)
                 self.handles.append(m.register_forward_hook(lambda mod, args, out: self._r(out)))
+        import re
+
+        def round_out(mod, args, out):
+            return [self._r(t) for t in out] if isinstance(out, (list, tuple)) else self._r(out)
+        for name, m in self.model.named_modules():
+            if isinstance(m, (TwoConvUnit, ThreeConvUnit, ExchangeModule)) or re.fullmatch(r"transition\d\.\d", name):
+                self.handles.append(m.register_forward_hook(round_out))
         return self.model
 
     def __exit__(self, *exc):

@@ -720,7 +720,7 @@ class Engine:
         # Block budget per launch: one block per CU.  (End to end, budgets of 128..256 measure the same within
         # run-to-run noise on MI355X, before and after the kernel was rebuilt: fewer blocks mean fewer slab bytes
         # but a longer launch; 96 and 384 are clearly worse.)
-        budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS", "256"))
+        budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS", "512"))   # round 3, grouped launches: 128 / 256 / 512 blocks = 17.65 / 16.03 / 15.36 ms per step (two 8-wave blocks per CU hide each other's tile latency)
         if ctile == 64:
             budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS64", "512"))
         elif kks == 1 and self.esz == 2:
