@@ -12,7 +12,7 @@ from stlpose_amd.engine import Engine, ParamStore
 
 FAM = {"stl_conv_forward": ("conv", "conv_ws", "conv1x1", "conv_core"), "stl_conv_wgrad": ("wgrad", "wgrad64"), "stl_fuse_forward": ("fuse_fwd",),
        "stl_fuse_backward": ("fuse_bwd",), "stl_upsample_backward": ("upsample_bwd",), "stl_patch3x3": ("patch",), "stl_head_forward": ("head_fwd",),
-       "stl_head_backward": ("head_bwd",), "stl_reduce_slabs_range": ("reduce_slabs",), "stl_bn_grads_range": ("bn_param",)}
+       "stl_head_backward": ("head_bwd",), "stl_reduce_slabs_range": ("reduce_slabs",), "stl_bn_grads_range": ("bn_param",), "stl_conv_wgrad_group": ("wgrad",)}
 
 
 def load_window(path):
@@ -59,7 +59,7 @@ def main():
             busy[strm] += d[i]
             for w in writes:
                 last[w] = i
-        off = sum(x for x, o in zip(d, sub) if o[0] in ("stl_conv_wgrad", "stl_reduce_slabs_range", "stl_bn_grads_range"))
+        off = sum(x for x, o in zip(d, sub) if o[0] in ("stl_conv_wgrad", "stl_conv_wgrad_group", "stl_reduce_slabs_range", "stl_bn_grads_range"))
         print(f"{label}: {len(sub)} ops, serial sum {sum(d) / 1e3:.2f} ms (off-chain {off / 1e3:.2f}), dependency-only critical path {max(fin_inf) / 1e3:.2f} ms, "
               f"in-order {len(sfin)}-stream simulation {max(fin_sim) / 1e3:.2f} ms (sync {sync} us); per-stream busy {[round(busy[s] / 1e3, 2) for s in sorted(busy)]}")
     print(f"outside the programs (weight_prep, fills, loss, optimiser): {other / 1e3:.2f} ms")
