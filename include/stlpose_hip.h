@@ -32,10 +32,14 @@ extern "C" {
 #define STL_SRC_PLAIN 0 /* v = x                                              */
 #define STL_SRC_BN 1    /* v = [relu](a*x + b), a,b from batch or running stats  */
 #define STL_SRC_BNBWD 2 /* v = a*(dt - r1/n - yhat*r2/n): BatchNorm backward on load */
+#define STL_SRC_BNADD 3 /* v = [relu](a*x + b + y): a residual block end z = ReLU(BN(x) + y) (HRnet.py:58-59) formed while the
+                           NEXT unit's first convolution stages its input; x = raw conv output, y = the skip tensor (same
+                           shape, PLAIN).  stl_conv_forward only (3x3 stride 1); with stl_conv.src_out the sum is also
+                           written out once, for the skip connection and the backward pass */
 
 typedef struct stl_src {
     const void* x;        /* PLAIN/BN: tensor; BNBWD: dt (grad wrt BN output, post ReLU mask) */
-    const void* y;        /* BNBWD: raw conv output the BN normalised                     */
+    const void* y;        /* BNBWD: raw conv output the BN normalised; BNADD: the tensor added after the BN */
     int32_t mode;         /* STL_SRC_*                                                    */
     int32_t relu;         /* BN: apply ReLU after the affine                              */
     const double* stats;  /* [NSHARD][2C] batch sum / sum-of-squares (train) or NULL (eval) */
@@ -87,12 +91,16 @@ typedef struct stl_conv {
     stl_src wg_h;          /* the conv's forward input (PLAIN or BN source), [B,Ho,Wo,C]     */
     float* wg_partial;     /* [wg_nsplit][C][9][C] or NULL                                  */
     int32_t wg_nsplit;
+    void* src_out;         /* BNADD source: [B,Hi,Wi,Ci] dtype -- the transformed source (the block-end sum) is stored here, every
+                              pixel by the one block whose tile owns it; NULL = not stored */
     int32_t grid_pct;      /* 0 / 100: default persistent-grid size; else per cent of it (the planner shrinks the grids of
                               launches that run beside other branches' launches: they share the CUs instead of queueing) */
 } stl_conv;
 int stl_conv_forward(const stl_conv* p, void* stream);
 /* Fill p->shape / p->TH / p->TW once (host-side tile search) so that launches are cheap. */
 int stl_conv_plan(stl_conv* p);
+/* 1 when stl_conv_forward has a kernel variant that takes p (already planned) with a STL_SRC_BNADD source. */
+int stl_conv_bnadd_ok(const stl_conv* p);
 /* Debug: phase time stamps (100 MHz ticks) of block 0 of the last conv launched with STL_CONV_STAMPS=1. */
 int stl_debug_conv_stamps(long long* host12);
 int stl_debug_conv_stamps2(long long* host64);

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("STLPOSE_HIP_LIB") or os.path.join(_HERE, "libstlpose_
 F32, BF16 = 0, 1
 NSHARD = 2
 WGRAD_GROUP_MAX = 8
-SRC_PLAIN, SRC_BN, SRC_BNBWD = 0, 1, 2
+SRC_PLAIN, SRC_BN, SRC_BNBWD, SRC_BNADD = 0, 1, 2, 3
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 
@@ -28,7 +28,7 @@ class Conv(C.Structure):
                 ("Co", i32), ("ks", i32), ("stride", i32), ("stuff", i32), ("TH", i32), ("TW", i32), ("shape", i32),
                 ("src", Src), ("w", vp), ("out", vp), ("bias", vp), ("out_relu", i32), ("out_stats", vp),
                 ("addend", vp), ("mask_y", vp), ("mask_bn", Src), ("red", vp), ("mask_z", vp),
-                ("wg_h", Src), ("partial", vp), ("wg_nsplit", i32), ("grid_pct", i32)]   # `partial` = wg_partial (fused weight gradient slabs)
+                ("wg_h", Src), ("partial", vp), ("wg_nsplit", i32), ("src_out", vp), ("grid_pct", i32)]   # `partial` = wg_partial (fused weight gradient slabs)
 
 
 class Wgrad(C.Structure):
@@ -109,6 +109,7 @@ OP_KIND = {"stl_conv_forward": 0, "stl_conv_wgrad": 1, "stl_fuse_forward": 2, "s
 SIGNATURES = {
     "stl_conv_forward": [C.POINTER(Conv), vp],
     "stl_conv_plan": [C.POINTER(Conv)],
+    "stl_conv_bnadd_ok": [C.POINTER(Conv)],
     "stl_debug_conv_stamps": [vp],
     "stl_debug_conv_stamps2": [vp],
     "stl_debug_wgrad_stamps": [vp],

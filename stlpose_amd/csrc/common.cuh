@@ -144,7 +144,7 @@ __device__ __forceinline__ void src_consts(const stl_src& s, int c, int C, float
     float mean, rstd;
     bn_mean_rstd(s, c, C, mean, rstd);
     const float g = s.gamma[c];
-    if (s.mode == STL_SRC_BN) {
+    if (s.mode == STL_SRC_BN || s.mode == STL_SRC_BNADD) {
         ca = g * rstd;
         cb = s.beta[c] - mean * ca;
         cc = 0.f;
@@ -203,7 +203,7 @@ __device__ __forceinline__ void bn_raw_finish(const stl_src& s, const SrcRaw& r,
 __device__ __forceinline__ void src_raw_load(const stl_src& s, int c, int C, SrcRaw& r) {
     if (s.mode == STL_SRC_PLAIN) return;
     bn_raw_load(s, c, C, r);
-    if (s.mode == STL_SRC_BN) {
+    if (s.mode == STL_SRC_BN || s.mode == STL_SRC_BNADD) {
         r.b = s.beta[c];
     } else {
 #pragma unroll
@@ -220,7 +220,7 @@ __device__ __forceinline__ void src_raw_finish(const stl_src& s, const SrcRaw& r
     }
     float mean, rstd;
     bn_raw_finish(s, r, mean, rstd);
-    if (s.mode == STL_SRC_BN) {
+    if (s.mode == STL_SRC_BN || s.mode == STL_SRC_BNADD) {
         ca = r.g * rstd;
         cb = r.b - mean * ca;
         cc = 0.f;

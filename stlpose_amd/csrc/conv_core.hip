@@ -123,13 +123,16 @@ __device__ __forceinline__ void store4(void* base, size_t elem, const float* f) 
 // the conv's forward input h (same halo geometry, staged once per tile).  dt and y are fetched once for both
 // gradients, one launch instead of two; every wave owns whole output tiles (no cross-wave reduction) and keeps
 // them in registers across the block's tiles; the block writes one split-K slab at the end.
-template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, int OCC, int WR, int NCO = 0>
+// ZM: the source is STL_SRC_BNADD (Q = true: second tensor on load): the staged value is the residual block end
+// z = ReLU(BN(x) + y); it is also written to p.src_out by the block that owns the pixel (tile interior, channel block 0).
+template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, int OCC, int WR, int NCO = 0, bool ZM = false>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const ConvK k) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTHR = 64 * WM * WN;
     constexpr int KV = ET<T>::KV, CK = ET<T>::CK, TAPS = KS * KS;
     constexpr bool FW = NCO > 0;
     static_assert(!FW || (KS == 3 && WM == 4 && WN == 1 && MT == 2 && NTW == 2 && Q), "fused weight gradient: 3x3, 128 px x 32 channels, BNBWD source");
+    static_assert(!ZM || (Q && KS == 3 && !FW), "block-end source: 3x3, two tensors on load");
     constexpr int NH = FW ? (sizeof(T) == 2 ? 1 : 2) : 1;   // 16-byte h vectors per staging slot (32 channels per pixel)
     constexpr int WKS = 4 * KV;                              // pixels per MFMA K step of the weight gradient
     constexpr int WNR = sizeof(T) == 2 ? 2 : 4;              // row offsets per transposed fragment
@@ -208,6 +211,15 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
         }
     }
     const int a_part = tid & 3;
+    uint32_t a_int = 0;   // ZM: bit i = staging slot i is a pixel of the tile interior (this block stores its z)
+    if constexpr (ZM) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i)
+            if (a_rc[i] >= 0) {
+                const int hr = a_rc[i] >> 16, hc = a_rc[i] & 0xffff;
+                if (hr >= 1 && hr <= k.TH && hc >= 1 && hc <= k.TW && by == 0 && p.src_out) a_int |= 1u << i;
+            }
+    }
     int b_g[NVB], b_l[NVB];
 #pragma unroll
     for (int i = 0; i < NVB; ++i) {
@@ -299,7 +311,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
             const bool ok = go[i] >= 0 && ch < p.Ci;
             const int chc = ok ? ch : 0;
             V16 val = ra[i];
-            if (Q)
+            if constexpr (ZM) {
+                val = xform_bnadd<T>(val, rq[i], cs + chc, cs + k.cipad + chc, relu_lo);
+                if (ok && ((a_int >> i) & 1u)) stg16((char*)p.src_out + (size_t)(go[i] + k0) * sizeof(T), val);   // z, once per pixel
+            } else if (Q)
                 val = xform_bnbwd<T>(val, rq[i], cs + chc, cs + k.cipad + chc, cs + 2 * k.cipad + chc);
             else if (p.src.mode != STL_SRC_PLAIN)
                 val = xform_bn<T>(val, cs + chc, cs + k.cipad + chc, relu_lo);
@@ -426,7 +441,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 
     // epilogue operands (addend / masks) of all MT tiles of the wave, fetched in one burst: before the MFMAs of the
     // tile's last chunk where the block owns its CU anyway (EPRE: 12 registers per tile), else at the start of the epilogue
-    constexpr bool EPRE = (OCC <= 1 && WM == 4 && WN == 2 && NTW == 2 && Q && !FW && sizeof(T) == 2);   // fp32 would need 96 registers and spills
+    constexpr bool EPRE = (OCC <= 1 && WM == 4 && WN == 2 && NTW == 2 && Q && !FW && !ZM && sizeof(T) == 2);   // fp32 would need 96 registers and spills
     auto epi_fetch = [&](int vr0, int c0, bool* pokv, size_t* pixv, EpiRaw<NTW>* er) __attribute__((always_inline)) {
         const int eb0 = fdiv(vr0, k.r_vp), ey0 = vr0 - eb0 * vpitch;
 #pragma unroll
@@ -584,15 +599,15 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 #include "conv_ws.inc"
 #include "conv1x1.inc"
 
-template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, int OCC = 1, int WR = -1, int NCO = 0>
+template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, int OCC = 1, int WR = -1, int NCO = 0, bool ZM = false>
 int launch(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, OCC, WR, NCO>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, OCC, WR, NCO, ZM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, OCC, WR, NCO>), grid, dim3(64 * WM * WN), lds, st, k);
+    hipLaunchKernelGGL((conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, OCC, WR, NCO, ZM>), grid, dim3(64 * WM * WN), lds, st, k);
     STL_LAUNCH_CHECK("conv_core");
     return 0;
 }
@@ -659,6 +674,21 @@ int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStrea
             break;
     }
     return stl_set_error("conv: no kernel variant for block shape %d with %d staging vectors per thread", shape, nva);
+}
+
+// block-end source (STL_SRC_BNADD): the shapes the two-conv units of the network are planned with -- 256 px x 32 co
+// (C <= 32), 256 px x 64 co (C = 64 / 128) and their small-map fallbacks; own instantiations, so that the
+// data-gradient kernels (Q without ZM) carry none of this
+static bool bnadd_shape_ok(int shape, int nva) { return nva <= 3 && (shape == 0 || shape == 2 || shape == 4 || shape == 8); }
+template <typename T>
+int dispatch_bnadd(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+    if (nva <= 3) switch (shape) {
+        case 0: return launch<T, 3, 4, 1, 2, 4, 3, true, 1, -1, 0, true>(k, grid, lds, st);
+        case 2: return launch<T, 3, 4, 2, 4, 2, 3, true, 1, -1, 0, true>(k, grid, lds, st);
+        case 4: return launch<T, 3, 4, 1, 2, 2, 3, true, 3, -1, 0, true>(k, grid, lds, st);
+        case 8: return launch<T, 3, 8, 1, 2, 2, 3, true, 3, -1, 0, true>(k, grid, lds, st);
+    }
+    return stl_set_error("conv: no block-end (BNADD) variant for block shape %d with %d staging vectors per thread", shape, nva);
 }
 
 struct Plan {
@@ -808,6 +838,14 @@ extern "C" int stl_conv_plan(stl_conv* pp) {
     return 0;
 }
 
+extern "C" int stl_conv_bnadd_ok(const stl_conv* pp) {
+    const stl_conv& p = *pp;
+    if (!(p.ks == 3 && p.stride == 1 && !p.stuff && p.shape >= 0 && p.shape < NSHAPES && p.TH > 0 && p.TW > 0) || use_1x1(p)) return 0;
+    const Shape sh = SHAPES[p.shape];
+    const int nva = ceil_div((p.TH + 2) * (p.TW + 2) * 4, sh.lthr);
+    return bnadd_shape_ok(p.shape, nva) ? 1 : 0;
+}
+
 extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     const stl_conv& p = *pp;
     STL_CHECK(p.dtype == STL_F32 || p.dtype == STL_BF16, "conv: bad dtype %d", p.dtype);
@@ -829,7 +867,11 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
                   "conv: output %dx%d inconsistent with input %dx%d ks %d stride %d", p.Ho, p.Wo, p.Hi, p.Wi, p.ks, p.stride);
     }
     STL_CHECK(p.src.x && p.w && p.out, "conv: null tensor pointer");
-    STL_CHECK(p.src.mode >= 0 && p.src.mode <= 2, "conv: bad src mode");
+    STL_CHECK(p.src.mode >= 0 && p.src.mode <= 3, "conv: bad src mode");
+    const bool zm = p.src.mode == STL_SRC_BNADD;
+    STL_CHECK(!zm || (p.ks == 3 && p.stride == 1 && !p.stuff && p.src.y && p.src.beta && (p.src.stats || (p.src.rmean && p.src.rvar)) && !p.wg_partial),
+              "conv: a BNADD source needs a 3x3 stride-1 convolution, the skip tensor in src.y and BatchNorm parameters");
+    STL_CHECK(zm || !p.src_out, "conv: src_out needs a BNADD source");
     STL_CHECK(p.src.mode == STL_SRC_PLAIN || p.src.gamma, "conv: BN source without gamma");
     STL_CHECK(p.src.mode != STL_SRC_BN || p.src.beta, "conv: BN source without beta");
     STL_CHECK(p.src.mode != STL_SRC_BN || p.src.stats || (p.src.rmean && p.src.rvar), "conv: BN source without statistics");
@@ -912,6 +954,8 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     const bool q = p.src.mode == STL_SRC_BNBWD;
     if (fused)
         return p.dtype == STL_BF16 ? dispatch_fused<__bf16>(k.nchunks, k, grid, lds, st) : dispatch_fused<float>(k.nchunks, k, grid, lds, st);
+    if (zm)
+        return p.dtype == STL_BF16 ? dispatch_bnadd<__bf16>(plan.shape, nva, k, grid, lds, st) : dispatch_bnadd<float>(plan.shape, nva, k, grid, lds, st);
 #define DISPATCH(T)                                                                                      \
     if (p.ks == 3)                                                                                       \
         return q ? dispatch<T, 3, true>(plan.shape, nva, k, grid, lds, st) : dispatch<T, 3, false>(plan.shape, nva, k, grid, lds, st); \

@@ -96,6 +96,7 @@ class Act:
     consumers: int = 0
     bwd_seen: int = 0                                        # consumers already handled by the backward builder
     fused_du: Optional[torch.Tensor] = None                  # plain: masked gradient produced by a fused dgrad
+    pending: Optional[Tuple] = None                          # plain block-end sum not consumed yet: (forward op, BN term, skip term)
 
     @property
     def ptr(self) -> int:
@@ -193,6 +194,7 @@ class Engine:
         return self._alloc(B * H * W * C * self.esz)
 
     def _src(self, a: Act, relu: Optional[bool] = None) -> capi.Src:
+        a.pending = None
         s = capi.Src()
         s.x = a.ptr
         if a.kind == "plain":
@@ -229,6 +231,11 @@ class Engine:
     # opt-in: measured 18.4 -> 18.8 ms/step -- every chain moved to another stream pays a cross-stream event wait
     # (~6 us) at both ends, more than the serialisation it removes
     balance_exchange = os.environ.get("STLPOSE_BALANCE_EXCHANGE", "0") != "0"
+    # block-end sums formed by the consuming conv1 (STL_SRC_BNADD).  Bit-identical to the two-launch form and time-neutral on
+    # MI355X (all 69 eligible sums merged: 15.50 vs 15.33-15.43 ms per step; C <= 32 / C <= 64 / C >= 64 / C >= 128 only:
+    # 15.53 / 15.51 / 15.45 / 15.36): the conv re-forms the sum for every halo pixel and every output-channel block, which
+    # costs what the saved launch and tensor pass bought.  Default: the C >= 128 layers (STLPOSE_MERGE_MINC / _MAXC).
+    merge_block_end = os.environ.get("STLPOSE_MERGE_BLOCK_END", "1") != "0"
 
     def est_cost(self, x: "Act", cout: int, ks: int, stride: int, hop: int = 0) -> float:
         """Estimated duration (us) of one conv of an exchange chain (arch._exchange_module): launch + latency chain
@@ -273,12 +280,29 @@ class Engine:
         p.TH, p.TW, p.shape = 0, 0, -1
         capi.call("stl_conv_plan", C.byref(p))  # block shape + pixel tile, searched once
         p.grid_pct = self._grid_pct(ck)
-        p.src = self._src(x)
+        reads, writes = [x.ptr], [y.ptr]
+        pend = x.pending
+        if (pend is not None and self.merge_block_end and kks == 3 and kstride == 1 and pend[0][2] == self._stream
+                and int(os.environ.get("STLPOSE_MERGE_MINC", "128")) <= x.C <= int(os.environ.get("STLPOSE_MERGE_MAXC", "4096"))
+                and capi.lib().stl_conv_bnadd_ok(C.byref(p)) == 1):
+            # Residual block end z = ReLU(BN(y2) + skip) whose FIRST consumer is this 3x3 convolution (the next unit's
+            # conv1): the sum is formed while the conv stages its tiles and written out once from the tile interiors
+            # (STL_SRC_BNADD + src_out) -- the stand-alone sum launch and one pass over the tensor go (HRnet.py:58-59).
+            fop, ybn, skip = pend
+            self.fwd_ops.remove(fop)
+            p.src = self._src(ybn, relu=True)
+            p.src.mode = capi.SRC_BNADD
+            p.src.y = skip.ptr
+            p.src_out = x.ptr
+            reads, writes = [ybn.ptr, skip.ptr], [y.ptr, x.ptr]
+            x.pending = None
+        else:
+            p.src = self._src(x)
         p.out = y.ptr
         if self.training:
             p.out_stats = self.stats.data_ptr() + 8 * bn.stats_off
         self._wk_fix.append((p, "w", ci.fwd_off))
-        self.fwd_ops.append(("stl_conv_forward", p, self._stream, [x.ptr], [y.ptr]))
+        self.fwd_ops.append(("stl_conv_forward", p, self._stream, reads, writes))
         x.consumers += 1
         self.tape.append(("conv", x, y, ci, (kks, kstride), self._stream))
         return y
@@ -299,8 +323,14 @@ class Engine:
             p.t[i].shift = s
             a.consumers += 1
         p.out = z.ptr
-        self.fwd_ops.append(("stl_fuse_forward", p, self._stream, [a.ptr for a, _, _ in terms], [z.ptr]))
+        op = ("stl_fuse_forward", p, self._stream, [a.ptr for a, _, _ in terms], [z.ptr])
+        self.fwd_ops.append(op)
         self.tape.append(("fuse", terms, z, relu, self._stream))
+        if relu and len(terms) == 2 and all(s == 0 for _, s, _ in terms):
+            bns = [a for a, _, tr in terms if a.kind == "bn" and not tr]
+            pls = [a for a, _, _ in terms if a.kind == "plain"]
+            if len(bns) == 1 and len(pls) == 1 and terms[0][0] is bns[0]:   # BN term first: same summation order as the sum kernel
+                z.pending = (op, bns[0], pls[0])
         return z
 
     def head(self, key, x: Act, joints) -> torch.Tensor:

@@ -609,3 +609,61 @@ def test_wgrad_group_equals_single_launches(case, dt):
     # a member of another shape is refused
     members[-1][0].Co += 8
     assert capi.lib().stl_conv_wgrad_group(C.byref(grp), stream()) != 0
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(4, 48, 36, 32, 32), (4, 24, 18, 64, 64), (3, 24, 18, 128, 128), (2, 12, 16, 16, 16), (2, 10, 4, 48, 48), (2, 13, 7, 32, 64)])
+def test_conv_block_end_source_bnadd(case, dt):
+    """STL_SRC_BNADD: z = ReLU(BN(y) + skip) formed while the 3x3 conv stages its input, and written out once
+    (src_out) -- against torch: conv2d(relu(batch_norm(y) + skip)) and the sum itself; and bit-identical to the
+    two-launch form (stl_fuse_forward, then the conv on the plain sum)."""
+    B, H, W, Ci, Co = case
+    code, td, tol = DT[dt]
+    torch.manual_seed(11)
+    y = torch.randn(B, Ci, H, W, device="cuda") * 1.5 + 0.3
+    skip = torch.relu(torch.randn(B, Ci, H, W, device="cuda"))
+    g, b = torch.rand(Ci, device="cuda") + 0.5, torch.randn(Ci, device="cuda") * 0.2
+    w = torch.randn(Co, Ci, 3, 3, device="cuda") * (2.0 / (Ci * 9)) ** 0.5
+    yt, st_, wt = nhwc(y, td), nhwc(skip, td), w.permute(0, 2, 3, 1).contiguous().to(td)     # [Co][tap][Ci]
+    stats = stats_of(yt, Ci)
+    zr = torch.relu(F.batch_norm(from_nhwc(yt, B, H, W, Ci), None, None, g, b, True, 0.0, EPS) + from_nhwc(st_, B, H, W, Ci))
+    ref = F.conv2d(from_nhwc(nhwc(zr, td), B, H, W, Ci), wt.float().permute(0, 3, 1, 2), padding=1)
+    out = torch.full((B * H * W * Co,), float("nan"), device="cuda", dtype=td)
+    z = torch.full((B * H * W * Ci,), float("nan"), device="cuda", dtype=td)
+    p = capi.Conv()
+    p.shape = -1
+    p.dtype, p.B, p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.Co, p.ks, p.stride = code, B, H, W, Ci, H, W, Co, 3, 1
+    capi.call("stl_conv_plan", C.byref(p))
+    if capi.lib().stl_conv_bnadd_ok(C.byref(p)) != 1:
+        pytest.skip(f"block shape {p.shape} has no block-end variant (the planner keeps the separate sum launch there)")
+    p.src = bn_src(yt, stats, g, b, B * H * W, True)
+    p.src.mode, p.src.y = capi.SRC_BNADD, st_.data_ptr()
+    p.src_out, p.w, p.out = z.data_ptr(), wt.data_ptr(), out.data_ptr()
+    ost = torch.zeros(capi.NSHARD * 2 * Co, dtype=torch.float64, device="cuda")
+    p.out_stats = ost.data_ptr()
+    capi.call("stl_conv_forward", C.byref(p), stream())
+    torch.cuda.synchronize()
+    assert not torch.isnan(z.float()).any() and not torch.isnan(out.float()).any()
+    assert relerr(from_nhwc(z, B, H, W, Ci), zr) < tol
+    assert relerr(from_nhwc(out, B, H, W, Co), ref) < tol
+    # two-launch form: the sum kernel, then the same conv on the plain tensor
+    f = capi.Fuse()
+    f.dtype, f.B, f.H, f.W, f.C, f.nterms, f.relu = code, B, H, W, Ci, 2, 1
+    f.t[0].src = bn_src(yt, stats, g, b, B * H * W, False)
+    f.t[1].src.x, f.t[1].src.mode = st_.data_ptr(), capi.SRC_PLAIN
+    z2 = torch.empty_like(z)
+    f.out = z2.data_ptr()
+    capi.call("stl_fuse_forward", C.byref(f), stream())
+    q = capi.Conv()
+    q.shape = -1
+    q.dtype, q.B, q.Hi, q.Wi, q.Ci, q.Ho, q.Wo, q.Co, q.ks, q.stride = code, B, H, W, Ci, H, W, Co, 3, 1
+    q.TH, q.TW, q.shape = p.TH, p.TW, p.shape
+    q.src.x, q.src.mode = z2.data_ptr(), capi.SRC_PLAIN
+    out2 = torch.empty_like(out)
+    ost2 = torch.zeros_like(ost)
+    q.w, q.out, q.out_stats = wt.data_ptr(), out2.data_ptr(), ost2.data_ptr()
+    capi.call("stl_conv_forward", C.byref(q), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(z, z2), "block-end sum differs from the sum kernel's"
+    assert torch.equal(out, out2), "conv over the merged source differs from conv over the materialised sum"
+    torch.testing.assert_close(ost.view(capi.NSHARD, -1).sum(0), ost2.view(capi.NSHARD, -1).sum(0), rtol=1e-12, atol=1e-9)
