@@ -359,11 +359,12 @@ def main():
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         sys.exit(subprocess.call(cmd, env=env))
 
-    # Before the first HIP call: the plan uses four compute streams = four hardware queues (the runtime's default
-    # maximum).  A RCCL communicator brings streams of its own; with only four queues they are multiplexed onto the
-    # compute queues and the step slows from 18.3 to 20.3 ms before a single collective is issued (measured with a
-    # one-rank communicator).  Eight queues remove that penalty and cost nothing at N = 1.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # Before the first HIP call: the plan uses four compute streams = four hardware queues, and four is all the chip runs at
+    # once (one queue per compute pipe) -- a FIFTH active queue is time-sliced against the others.  With the runtime's
+    # default GPU_MAX_HW_QUEUES=4 the streams of a RCCL communicator are multiplexed onto the four compute queues (one-rank
+    # rehearsal of the bucketed all-reduce path, round 3: 15.39 ms per step with the collectives vs 15.44 without); with 8
+    # they become queues of their own and the same step takes 23.7 ms (5 / 6 queues: 22.4 / 22.1).  Keep four.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

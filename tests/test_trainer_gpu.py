@@ -150,3 +150,55 @@ def test_checkpoints_hold_the_trained_weights_and_sgd_resume_keeps_momentum(tmp_
     gg = g + wd * w0
     expect = w0 - float(t2.lr) * (0.9 * mom + gg)      # b = mu * b_loaded + g ; p -= lr * b   (no Nesterov)
     assert torch.allclose(t2.ts.store.master, expect, rtol=1e-4, atol=1e-7)
+
+
+def _two_rank_worker(rank, world, port, exp, q):
+    """One of two ranks sharing the box's GPU (gloo rendezvous; the collectives move GPU tensors through the host)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, H, W = 2, 64, 64
+        # UNEVEN shards: rank 0 has 3 training batches, rank 1 has 5 -- every rank must take 3 steps per epoch
+        train = _loader(3 + 2 * rank, B, H, W, 10 + rank)
+        valid = _loader(5, B, H, W, 20 + rank)
+        torch.manual_seed(100 + rank)       # different initial weights per rank: the broadcast must equalise them
+        t = Trainer(exp, _exp_data(2, H, W), train, valid, B, arch="tiny", compute_dtype="fp32", process_group=dist.group.WORLD)
+        t.setup_model()
+        t.training_loop()
+        torch.cuda.synchronize()
+        w = torch.cat([p.detach().flatten() for p in t.model.parameters()]).cpu()
+        bufs = t.ts.store.bufs.detach().cpu()
+        q.put((rank, t.iterations, w, float(t.lr), float(t.train_loss), bufs[:64].clone()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_two_ranks_uneven_loaders_stay_in_step(tmp_path):
+    """the one-process-per-GPU paths of the Trainer on MORE than one rank -- state broadcast, bucketed
+    all-reduce per step, rank-averaged epoch statistics, rank-0-only checkpoints -- with loaders of different lengths
+    (would deadlock without _common_steps).  Both ranks end with identical weights and learning rate."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    exp = str(tmp_path / "dp")
+    os.makedirs(exp)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, exp, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda r: r[0])
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    (r0, it0, w0, lr0, tl0, b0), (r1, it1, w1, lr1, tl1, b1) = res
+    assert it0 == it1 == 6, (it0, it1)                      # 2 epochs x min(3, 5) steps
+    assert torch.equal(w0, w1), f"replicas diverged: max diff {float((w0 - w1).abs().max())}"
+    assert lr0 == lr1 and tl0 == tl1                          # epoch statistics are rank averages on both
+    assert not torch.equal(b0, b1)                            # BatchNorm statistics stay per replica (nn.DataParallel keeps replica 0's)
+    names = sorted(os.listdir(os.path.join(exp, "models")))
+    assert names == ["checkpoint_epoch_0.pth", "checkpoint_epoch_1.pth", "checkpoint_epoch_final.pth"]
