@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 #include "common.cuh"
 
 namespace {
@@ -125,7 +126,8 @@ __device__ __forceinline__ void store4(void* base, size_t elem, const float* f) 
 // them in registers across the block's tiles; the block writes one split-K slab at the end.
 // ZM: the source is STL_SRC_BNADD (Q = true: second tensor on load): the staged value is the residual block end
 // z = ReLU(BN(x) + y); it is also written to p.src_out by the block that owns the pixel (tile interior, channel block 0).
-template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, int OCC, int WR, int NCO = 0, bool ZM = false>
+// PE: plain epilogue -- the launch has no bias / addend / mask operand (conv_common.inc, epilogue_apply).
+template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, bool PE, int OCC, int WR, int NCO = 0, bool ZM = false>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const ConvK k) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTHR = 64 * WM * WN;
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
             if (c < p.Ci) src_consts(p.src, c, p.Ci, a, b, cc);
             cs[c] = a, cs[k.cipad + c] = b, cs[2 * k.cipad + c] = cc;
         }
-        if (p.mask_y) {
+        if (!PE && p.mask_y) {
             // the LAST wave computes the mask constants while the first one(s) do the source's: the two sets are
             // dependent global round trips each, and run in parallel on different waves instead of back to back
             for (int c = tid - (NTHR - 64); c >= 0 && c < BCO; c += 64) {
@@ -250,9 +252,19 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     const int woff = (wn * NTW * 16 + r16) * ROWB + g * 16;
 
     STAMP(2);
-    V16 ra[NVA], rq[Q ? NVA : 1], rb[NVB];
+    // NSET register sets of staged loads: the loads of stage s + NSET are issued while stage s is multiplied, so a
+    // stage's memory round trip (2-5 us when every block of a launch asks at once; 45-49 % of a wave's cycles were spent
+    // parked behind it with one set) is spread over NSET iterations.  One set for the fused backward (registers) and
+    // for the 4-wave shapes compiled for three or four blocks per CU (they hide the latency with residency).
+#ifndef STL_NSET2
+#define STL_NSET2 0   // two sets measured neutral-to-slower (serial 21.39 vs 21.26 ms, step 15.23 vs 15.18): kept behind the macro
+#endif
+    constexpr int NSET = (!STL_NSET2 || Q || FW || (WM * WN == 4 && OCC >= 3) || (WM == 8 && MT == 2)) ? 1 : 2;   // Q: two tensors per slot -- the 8-wave data-gradient shapes sit at 249 of 256 registers with one set
+    V16 ra[NSET][NVA], rq[NSET][Q ? NVA : 1], rb[NSET][NVB];
     V16 rh[FW ? NVA : 1][NH];
-    int a_go[NVA];
+    int a_go[NSET][NVA];
+    int st_t[NSET], st_ch[NSET];      // the stage (tile, chunk) each set holds
+    bool st_have[NSET];
 
     auto tile_setup = [&](int t, int* go) {
         const int tr = fdiv(t, k.r_tc), tc = t - tr * k.tiles_c;
@@ -280,13 +292,14 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     // Loads are UNCONDITIONAL (invalid slots read element 0 and are zeroed at write time): a
     // guarded load makes hipcc branch around it and wait vmcnt(0) per element, which serialises
     // the whole staging burst into dependent round trips.
-    auto issue = [&](const int* go, int k0, bool en) {
+    auto issue = [&](auto SET, const int* go, int k0, bool en) __attribute__((always_inline)) {
+        constexpr int S = decltype(SET)::value;
         const bool chok = en && (k0 + a_part * KV) < p.Ci;
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
             const int off = (go[i] >= 0 && chok) ? go[i] + k0 : 0;
-            ra[i] = ldg16((const char*)p.src.x + (size_t)off * sizeof(T));
-            if (Q) rq[i] = ldg16((const char*)p.src.y + (size_t)off * sizeof(T));
+            ra[S][i] = ldg16((const char*)p.src.x + (size_t)off * sizeof(T));
+            if (Q) rq[S][i] = ldg16((const char*)p.src.y + (size_t)off * sizeof(T));
             if constexpr (FW) {   // h slab of the same halo pixel (Ci == Co): only with the first chunk of a tile
                 const int hoff = (go[i] >= 0 && en && k0 == 0) ? go[i] + n0 : 0;
 #pragma unroll
@@ -297,25 +310,26 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 #pragma unroll
             for (int i = 0; i < NVB; ++i) {
                 const bool ok = en && b_g[i] >= 0 && (k0 + ((tid + i * NTHR) & 3) * KV) < p.Ci;
-                rb[i] = ldg16((const char*)p.w + (size_t)(ok ? b_g[i] + k0 : 0) * sizeof(T));
+                rb[S][i] = ldg16((const char*)p.w + (size_t)(ok ? b_g[i] + k0 : 0) * sizeof(T));
             }
         }
     };
     const float relu_lo = p.src.relu ? 0.f : -INFINITY;
     const float relu_lo_h = (FW && p.wg_h.relu) ? 0.f : -INFINITY;
-    auto write_lds = [&](const int* go, int k0) {
+    auto write_lds = [&](auto SET, const int* go, int k0) __attribute__((always_inline)) {
+        constexpr int S = decltype(SET)::value;
         const int ch = k0 + a_part * KV;
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
             if (a_rc[i] < 0) continue;
             const bool ok = go[i] >= 0 && ch < p.Ci;
             const int chc = ok ? ch : 0;
-            V16 val = ra[i];
+            V16 val = ra[S][i];
             if constexpr (ZM) {
-                val = xform_bnadd<T>(val, rq[i], cs + chc, cs + k.cipad + chc, relu_lo);
+                val = xform_bnadd<T>(val, rq[S][i], cs + chc, cs + k.cipad + chc, relu_lo);
                 if (ok && ((a_int >> i) & 1u)) stg16((char*)p.src_out + (size_t)(go[i] + k0) * sizeof(T), val);   // z, once per pixel
             } else if (Q)
-                val = xform_bnbwd<T>(val, rq[i], cs + chc, cs + k.cipad + chc, cs + 2 * k.cipad + chc);
+                val = xform_bnbwd<T>(val, rq[S][i], cs + chc, cs + k.cipad + chc, cs + 2 * k.cipad + chc);
             else if (p.src.mode != STL_SRC_PLAIN)
                 val = xform_bn<T>(val, cs + chc, cs + k.cipad + chc, relu_lo);
             mask16(val, ok);  // zero padding applies AFTER the transform
@@ -338,7 +352,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 #pragma unroll
             for (int i = 0; i < NVB; ++i) {
                 const bool ok = b_g[i] >= 0 && (k0 + ((tid + i * NTHR) & 3) * KV) < p.Ci;
-                V16 val = rb[i];
+                V16 val = rb[S][i];
                 mask16(val, ok);
                 if (tid + i * NTHR < BCO * TAPS * 4) *reinterpret_cast<V16*>(sB + b_l[i]) = val;
             }
@@ -349,7 +363,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
             const bool ok = b_g[i] >= 0 && (((tid + i * NTHR) & 3) * KV) < p.Ci;
-            rb[i] = ldg16((const char*)p.w + (size_t)(ok ? b_g[i] : 0) * sizeof(T));
+            rb[0][i] = ldg16((const char*)p.w + (size_t)(ok ? b_g[i] : 0) * sizeof(T));
         }
     }
 
@@ -364,18 +378,37 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     const int T8 = (k.npt + 7) >> 3;
     const int vpitch = p.Ho + 1;
 
-    int it = lx;
-    int t = xcd * T8 + it;
-    int ch0 = 0;
-    bool have = (it < T8) && (t < k.npt);
+    // cursor of the NEXT stage to request: tiles it_n = lx, lx + nx, ... of this XCD's share, chunks 0 .. nchunks-1 of each
+    int it_n = lx, t_n = xcd * T8 + lx, ch_n = 0;
+    bool have_n = (it_n < T8) && (t_n < k.npt);
+    constexpr std::integral_constant<int, 0> I0{};
+    constexpr std::integral_constant<int, NSET - 1> I1{};
+    // request the cursor's stage into set S, remember which stage the set now holds, advance the cursor
+    auto prefetch = [&](auto SET) __attribute__((always_inline)) {
+        constexpr int S = decltype(SET)::value;
+        if (have_n) {
+            if (ch_n == 0) {
+                tile_setup(t_n, a_go[S]);
+            } else if (NSET == 2 && ch_n == 1) {   // chunk 0 of this tile went to the other set: same tile, same offsets
+#pragma unroll
+                for (int i = 0; i < NVA; ++i) a_go[S][i] = a_go[S ^ (NSET - 1)][i];
+            }
+        }
+        st_t[S] = t_n, st_ch[S] = ch_n, st_have[S] = have_n;
+        issue(SET, a_go[S], ch_n * CK, have_n);
+        if (++ch_n == k.nchunks) {
+            ch_n = 0, it_n += nx, t_n = xcd * T8 + it_n;
+            have_n = have_n && (it_n < T8) && (t_n < k.npt);
+        }
+    };
     STAMP(3);
-    if (have) tile_setup(t, a_go);
-    issue(a_go, 0, have);
+    prefetch(I0);
+    if constexpr (NSET == 2) prefetch(I1);
     if (wres) {
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
             const bool ok = b_g[i] >= 0 && (((tid + i * NTHR) & 3) * KV) < p.Ci;
-            V16 val = rb[i];
+            V16 val = rb[0][i];
             mask16(val, ok);
             if (tid + i * NTHR < BCO * TAPS * 4) *reinterpret_cast<V16*>(sB + b_l[i]) = val;
         }
@@ -441,7 +474,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 
     // epilogue operands (addend / masks) of all MT tiles of the wave, fetched in one burst: before the MFMAs of the
     // tile's last chunk where the block owns its CU anyway (EPRE: 12 registers per tile), else at the start of the epilogue
-    constexpr bool EPRE = (OCC <= 1 && WM == 4 && WN == 2 && NTW == 2 && Q && !FW && !ZM && sizeof(T) == 2);   // fp32 would need 96 registers and spills
+    constexpr bool EPRE = (OCC <= 1 && WM == 4 && WN == 2 && NTW == 2 && Q && !PE && !FW && !ZM && sizeof(T) == 2);   // fp32 would need 96 registers and spills
     auto epi_fetch = [&](int vr0, int c0, bool* pokv, size_t* pixv, EpiRaw<NTW>* er) __attribute__((always_inline)) {
         const int eb0 = fdiv(vr0, k.r_vp), ey0 = vr0 - eb0 * vpitch;
 #pragma unroll
@@ -459,29 +492,24 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
         }
     };
 
-    // flat loop over stages (tile, chunk); exactly ONE issue() site inside the loop so that the
-    // staging registers need no PHI copies (which would force a vmcnt(0) before the MFMAs)
-    while (have) {
+    // flat loop over stages (tile, chunk), unrolled over the register sets; exactly ONE issue() site per set inside
+    // the loop so that the staging registers need no PHI copies (which would force a vmcnt(0) before the MFMAs)
+    auto stage = [&](auto SET) __attribute__((always_inline)) {
+        constexpr int S = decltype(SET)::value;
+        const int t = st_t[S], ch0 = st_ch[S];
         const int tr = fdiv(t, k.r_tc), tc = t - tr * k.tiles_c;
         const int vr0 = tr * k.TH, c0 = tc * k.TW;
-        write_lds(a_go, ch0 * CK);
+        write_lds(SET, a_go[S], ch0 * CK);
         __syncthreads();
         if (ch0 == 0) STAMP(5);
         const bool last_chunk = (ch0 + 1 == k.nchunks);
-        int itn = it, tn = t, chn = ch0 + 1;
-        bool have_n = true;
-        if (last_chunk) {
-            itn = it + nx, tn = xcd * T8 + itn, chn = 0;
-            have_n = (itn < T8) && (tn < k.npt);
-            if (have_n) tile_setup(tn, a_go);
-        }
         bool pokv[EPRE ? MT : 1];
         size_t pixv[EPRE ? MT : 1];
         EpiRaw<NTW> er[EPRE ? MT : 1];
         if constexpr (EPRE) {
-            if (last_chunk) epi_fetch(vr0, c0, pokv, pixv, er);   // ahead of the next stage's loads: consumed behind a counted wait
+            if (last_chunk) epi_fetch(vr0, c0, pokv, pixv, er);   // ahead of the next loads: consumed behind a counted wait
         }
-        issue(a_go, chn * CK, have_n);  // next stage's loads land during the MFMAs below
+        prefetch(SET);  // stage s + NSET into the set just drained: its loads land during the MFMAs of this and the next stage
         if (ch0 == 0) STAMP(6);
         {  // fragment reads of tap t+1 are issued before the MFMAs of tap t (static double buffer).  PIN: the order is
            // pinned with scheduling barriers -- left alone, the scheduler sinks every read to just in front of its
@@ -536,12 +564,19 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
                         pok = (b < p.B) && (oy < p.Ho) && (c < p.Wo);
                     }
                     const size_t pix = pok ? (((size_t)b * p.Ho + oy) * p.Wo + c) * p.Co : 0;
-                    epilogue_tile<T, NTW, BCO>(p, acc[mi], cm, pok, pix, n0, wn * NTW * 16, g, s0, s1);
+                    epilogue_tile<T, NTW, BCO, PE>(p, acc[mi], cm, pok, pix, n0, wn * NTW * 16, g, s0, s1);
                 }
             }
         }
         if (last_chunk) STAMP(9);
-        it = itn, t = tn, ch0 = chn, have = have_n;
+    };
+    while (true) {
+        if (!st_have[0]) break;
+        stage(I0);
+        if constexpr (NSET == 2) {
+            if (!st_have[1]) break;
+            stage(I1);
+        }
     }
     STAMP(10);
     // ---- flush statistics: lanes of one 16-lane group hold the same channels -> xor-reduce them,
@@ -599,15 +634,15 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 #include "conv_ws.inc"
 #include "conv1x1.inc"
 
-template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, int OCC = 1, int WR = -1, int NCO = 0, bool ZM = false>
+template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, bool PE, int OCC = 1, int WR = -1, int NCO = 0, bool ZM = false>
 int launch(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, OCC, WR, NCO, ZM>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, NCO, ZM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, OCC, WR, NCO, ZM>), grid, dim3(64 * WM * WN), lds, st, k);
+    hipLaunchKernelGGL((conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, NCO, ZM>), grid, dim3(64 * WM * WN), lds, st, k);
     STL_LAUNCH_CHECK("conv_core");
     return 0;
 }
@@ -616,9 +651,9 @@ int launch(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
 template <typename T>
 int dispatch_fused(int nco, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     switch (nco) {
-        case 1: return launch<T, 3, 4, 1, 2, 2, 3, true, 2, 1, 1>(k, grid, lds, st);    // bf16 C = 32: filters resident
-        case 2: return launch<T, 3, 4, 1, 2, 2, 3, true, 2, -1, 2>(k, grid, lds, st);   // bf16 C = 64 / fp32 C = 32
-        case 4: return launch<T, 3, 4, 1, 2, 2, 3, true, 1, -1, 4>(k, grid, lds, st);   // fp32 C = 64
+        case 1: return launch<T, 3, 4, 1, 2, 2, 3, true, false, 2, 1, 1>(k, grid, lds, st);    // bf16 C = 32: filters resident
+        case 2: return launch<T, 3, 4, 1, 2, 2, 3, true, false, 2, -1, 2>(k, grid, lds, st);   // bf16 C = 64 / fp32 C = 32
+        case 4: return launch<T, 3, 4, 1, 2, 2, 3, true, false, 1, -1, 4>(k, grid, lds, st);   // fp32 C = 64
     }
     return stl_set_error("conv(fused): %d chunks not supported", nco);
 }
@@ -637,30 +672,30 @@ constexpr Shape SHAPES[NSHAPES] = {{128, 64, 256, 0, 256, 9}, {512, 32, 512, 0, 
                                    {512, 32, 512, 1, 256, 10}, {256, 64, 512, 1, 256, 6}, {128, 64, 512, 1, 256, 9},
                                    {256, 32, 512, 0, 512, 3}};
 
-template <typename T, int KS, bool Q>
+template <typename T, int KS, bool Q, bool PE>
 int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     switch (shape) {
         case 0:
-            if (nva <= 3) return launch<T, KS, 4, 1, 2, 4, 3, Q>(k, grid, lds, st);
-            if (nva <= 9) return launch<T, KS, 4, 1, 2, 4, 9, Q>(k, grid, lds, st);
+            if (nva <= 3) return launch<T, KS, 4, 1, 2, 4, 3, Q, PE>(k, grid, lds, st);
+            if (nva <= 9) return launch<T, KS, 4, 1, 2, 4, 9, Q, PE>(k, grid, lds, st);
             break;
         case 1:
-            if (nva <= 6) return launch<T, KS, 8, 1, 4, 2, 6, Q>(k, grid, lds, st);
+            if (nva <= 6) return launch<T, KS, 8, 1, 4, 2, 6, Q, PE>(k, grid, lds, st);
             break;
         case 2:
-            if (nva <= 3) return launch<T, KS, 4, 2, 4, 2, 3, Q>(k, grid, lds, st);
+            if (nva <= 3) return launch<T, KS, 4, 2, 4, 2, 3, Q, PE>(k, grid, lds, st);
             break;
         case 3:
-            if (nva <= 3) return launch<T, KS, 4, 2, 4, 4, 3, Q>(k, grid, lds, st);
+            if (nva <= 3) return launch<T, KS, 4, 2, 4, 4, 3, Q, PE>(k, grid, lds, st);
             break;
-        case 8:
-            if (nva <= 3 && k.wres) return launch<T, KS, 8, 1, 2, 2, 3, Q, 4, 1>(k, grid, lds, st);
-            if (nva <= 3) return launch<T, KS, 8, 1, 2, 2, 3, Q, (Q ? 3 : 4)>(k, grid, lds, st);
+        case 8:   // forward (two register sets of staged loads): three waves per SIMD, no spills
+            if (nva <= 3 && k.wres) return launch<T, KS, 8, 1, 2, 2, 3, Q, PE, 4, 1>(k, grid, lds, st);
+            if (nva <= 3) return launch<T, KS, 8, 1, 2, 2, 3, Q, PE, (Q ? 3 : 4)>(k, grid, lds, st);
             break;
         case 4:
-            if (nva <= 3 && k.wres) return launch<T, KS, 4, 1, 2, 2, 3, Q, 4, 1>(k, grid, lds, st);  // 113-123 VGPRs, no spills
-            if (nva <= 3) return launch<T, KS, 4, 1, 2, 2, 3, Q, (Q ? 3 : 4)>(k, grid, lds, st);
-            if (nva <= 6) return launch<T, KS, 4, 1, 2, 2, 6, Q, 3>(k, grid, lds, st);
+            if (nva <= 3 && k.wres) return launch<T, KS, 4, 1, 2, 2, 3, Q, PE, 4, 1>(k, grid, lds, st);  // 113-123 VGPRs, no spills
+            if (nva <= 3) return launch<T, KS, 4, 1, 2, 2, 3, Q, PE, (Q ? 3 : 4)>(k, grid, lds, st);
+            if (nva <= 6) return launch<T, KS, 4, 1, 2, 2, 6, Q, PE, 3>(k, grid, lds, st);
             break;
         case 5:
             if (nva <= 10) return launch_ws<T, KS, 8, 2, 10, Q>(k, grid, lds, st);
@@ -683,10 +718,10 @@ static bool bnadd_shape_ok(int shape, int nva) { return nva <= 3 && (shape == 0 
 template <typename T>
 int dispatch_bnadd(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     if (nva <= 3) switch (shape) {
-        case 0: return launch<T, 3, 4, 1, 2, 4, 3, true, 1, -1, 0, true>(k, grid, lds, st);
-        case 2: return launch<T, 3, 4, 2, 4, 2, 3, true, 1, -1, 0, true>(k, grid, lds, st);
-        case 4: return launch<T, 3, 4, 1, 2, 2, 3, true, 3, -1, 0, true>(k, grid, lds, st);
-        case 8: return launch<T, 3, 8, 1, 2, 2, 3, true, 3, -1, 0, true>(k, grid, lds, st);
+        case 0: return launch<T, 3, 4, 1, 2, 4, 3, true, true, 1, -1, 0, true>(k, grid, lds, st);
+        case 2: return launch<T, 3, 4, 2, 4, 2, 3, true, true, 1, -1, 0, true>(k, grid, lds, st);
+        case 4: return launch<T, 3, 4, 1, 2, 2, 3, true, true, 3, -1, 0, true>(k, grid, lds, st);
+        case 8: return launch<T, 3, 8, 1, 2, 2, 3, true, true, 3, -1, 0, true>(k, grid, lds, st);
     }
     return stl_set_error("conv: no block-end (BNADD) variant for block shape %d with %d staging vectors per thread", shape, nva);
 }
@@ -872,6 +907,7 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     STL_CHECK(!zm || (p.ks == 3 && p.stride == 1 && !p.stuff && p.src.y && p.src.beta && (p.src.stats || (p.src.rmean && p.src.rvar)) && !p.wg_partial),
               "conv: a BNADD source needs a 3x3 stride-1 convolution, the skip tensor in src.y and BatchNorm parameters");
     STL_CHECK(zm || !p.src_out, "conv: src_out needs a BNADD source");
+    STL_CHECK(!zm || (!p.bias && !p.addend && !p.mask_y && !p.mask_z && !p.red), "conv: a BNADD source takes no epilogue operands");
     STL_CHECK(p.src.mode == STL_SRC_PLAIN || p.src.gamma, "conv: BN source without gamma");
     STL_CHECK(p.src.mode != STL_SRC_BN || p.src.beta, "conv: BN source without beta");
     STL_CHECK(p.src.mode != STL_SRC_BN || p.src.stats || (p.src.rmean && p.src.rvar), "conv: BN source without statistics");
@@ -956,10 +992,14 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
         return p.dtype == STL_BF16 ? dispatch_fused<__bf16>(k.nchunks, k, grid, lds, st) : dispatch_fused<float>(k.nchunks, k, grid, lds, st);
     if (zm)
         return p.dtype == STL_BF16 ? dispatch_bnadd<__bf16>(plan.shape, nva, k, grid, lds, st) : dispatch_bnadd<float>(plan.shape, nva, k, grid, lds, st);
+    const bool plain = !p.bias && !p.addend && !p.mask_y && !p.mask_z && !p.red;   // forward convs of the pose network
 #define DISPATCH(T)                                                                                      \
-    if (p.ks == 3)                                                                                       \
-        return q ? dispatch<T, 3, true>(plan.shape, nva, k, grid, lds, st) : dispatch<T, 3, false>(plan.shape, nva, k, grid, lds, st); \
-    return q ? dispatch<T, 1, true>(plan.shape, nva, k, grid, lds, st) : dispatch<T, 1, false>(plan.shape, nva, k, grid, lds, st);
+    if (p.ks == 3) {                                                                                     \
+        if (q) return dispatch<T, 3, true, false>(plan.shape, nva, k, grid, lds, st);                    \
+        return plain ? dispatch<T, 3, false, true>(plan.shape, nva, k, grid, lds, st) : dispatch<T, 3, false, false>(plan.shape, nva, k, grid, lds, st); \
+    }                                                                                                    \
+    if (q) return dispatch<T, 1, true, false>(plan.shape, nva, k, grid, lds, st);                        \
+    return plain ? dispatch<T, 1, false, true>(plan.shape, nva, k, grid, lds, st) : dispatch<T, 1, false, false>(plan.shape, nva, k, grid, lds, st);
     if (p.dtype == STL_BF16) {
         DISPATCH(__bf16)
     } else {

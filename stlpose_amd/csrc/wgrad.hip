@@ -386,6 +386,8 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(const WgK k) {
     constexpr int NVG = TPX * VPX / 256;    // g staging vectors per thread
     constexpr int NKS = TPX / KSTEP;        // K steps per tile, all done by every wave
     const stl_wgrad& p = k.p;
+    const int member = blockIdx.x / p.nsplit, bsplit = blockIdx.x - member * p.nsplit;   // grouped launch, see wgrad_kernel
+    const stl_wgrad_io& io = k.io[member];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
     const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
@@ -473,16 +475,16 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(const WgK k) {
 #pragma unroll
         for (int i = 0; i < NVG; ++i) {
             const size_t off = (en && g_go[i] >= 0) ? (size_t)g_go[i] : 0;
-            rgv[i] = ldg16((const char*)p.g.x + off * sizeof(T));
-            if (GQ) rgq[i] = ldg16((const char*)p.g.y + off * sizeof(T));
+            rgv[i] = ldg16((const char*)io.g.x + off * sizeof(T));
+            if (GQ) rgq[i] = ldg16((const char*)io.g.y + off * sizeof(T));
         }
 #pragma unroll
         for (int i = 0; i < NVH; ++i) {
             const size_t off = (en && h_go[i] >= 0) ? (size_t)h_go[i] : 0;
-            rhv[i] = ldg16((const char*)p.h.x + off * sizeof(T));
+            rhv[i] = ldg16((const char*)io.h.x + off * sizeof(T));
         }
     };
-    const float relu_lo = p.h.relu ? 0.f : -INFINITY;
+    const float relu_lo = io.h.relu ? 0.f : -INFINITY;
     auto write_lds = [&]() {
         const int cl = g_part * KV;
 #pragma unroll
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(const WgK k) {
         for (int i = 0; i < NVH; ++i) {
             if (h_rc[i] < 0) continue;
             V16 val = rhv[i];
-            if (p.h.mode == STL_SRC_BN) val = xform_bn<T>(val, chc + cl, chc + 64 + cl, relu_lo);
+            if (io.h.mode == STL_SRC_BN) val = xform_bn<T>(val, chc + cl, chc + 64 + cl, relu_lo);
             mask16(val, h_go[i] >= 0);
             const int v = tid + i * 256;
             *reinterpret_cast<V16*>(sH + (v / VPX) * k.psh + g_part * 16) = val;
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(const WgK k) {
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) acc[a][b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int t = blockIdx.x;
+    int t = bsplit;
     bool have = t < k.npt;
     WSTAMP(1);
     // BatchNorm constants (wave 3: the 64 channels of g, wave 2: those of h): statistics loads go out
@@ -521,8 +523,8 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(const WgK k) {
     const bool cw = wave >= 2, cg = wave == 3;
     const bool cok = cw && (cg ? co0 + lane < p.Co : ci0 + lane < p.Ci);
     if (cok) {
-        if (cg) src_raw_load(p.g, co0 + lane, p.Co, raw);
-        else src_raw_load(p.h, ci0 + lane, p.Ci, raw);
+        if (cg) src_raw_load(io.g, co0 + lane, p.Co, raw);
+        else src_raw_load(io.h, ci0 + lane, p.Ci, raw);
     }
     if (have) setup(t);
     issue(have);
@@ -530,8 +532,8 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(const WgK k) {
     if (cw) {
         float a = 0.f, b = 0.f, cc = 0.f;
         if (cok) {
-            if (cg) src_raw_finish(p.g, raw, a, b, cc);
-            else src_raw_finish(p.h, raw, a, b, cc);
+            if (cg) src_raw_finish(io.g, raw, a, b, cc);
+            else src_raw_finish(io.h, raw, a, b, cc);
         }
         if (cg) cgc[lane] = a, cgc[64 + lane] = b, cgc[128 + lane] = cc;
         else chc[lane] = a, chc[64 + lane] = b;
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(const WgK k) {
         write_lds();
         __syncthreads();
         if (first) WSTAMP(4);
-        const int tn = t + gridDim.x;
+        const int tn = t + p.nsplit;
         const bool have_n = tn < k.npt;
         if (have_n) setup(tn);
         issue(have_n);  // next tile's loads fly during the MFMAs
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(const WgK k) {
     WSTAMP(6);
     // ---- every wave writes its quadrant: acc[mt][nt][tap][r] = dw[co = 4g + r][ci = lane & 15]
     {
-        float* slab = p.partial + (size_t)blockIdx.x * p.Co * TAPS * p.Ci;
+        float* slab = io.partial + (size_t)bsplit * p.Co * TAPS * p.Ci;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -693,7 +695,6 @@ extern "C" int stl_conv_wgrad_group(const stl_wgrad_group* grp, void* stream) {
                       b.g.mode == a.g.mode,
                   "wgrad_group: member %d differs from member 0 in geometry, tile, nsplit or gradient source mode", i);
     }
-    STL_CHECK(grp->n == 1 || wgrad_chunk(a) == 32, "wgrad_group: the 64 x 64-channel variant is not grouped");
     return wgrad_run(grp->p, grp->n, stream);
 }
 
@@ -742,7 +743,7 @@ static int wgrad_run(const stl_wgrad* const* ps, int ng, void* stream) {
         const size_t lds64 = (size_t)k.off_h + (size_t)k.HP * k.psh;
         STL_CHECK(lds64 <= 160 * 1024, "wgrad64: tile needs %zu B of LDS (>160 KiB)", lds64);
         STL_CHECK(p.nsplit <= k.npt || p.nsplit == 1, "wgrad: nsplit %d > tiles %d", p.nsplit, k.npt);
-        dim3 grid64(p.nsplit, ceil_div(p.Co, 64), ceil_div(p.Ci, 64));   // never grouped (ng == 1)
+        dim3 grid64(p.nsplit * ng, ceil_div(p.Co, 64), ceil_div(p.Ci, 64));
         return p.ks == 3 ? dispatch64<3>(k, grid64, lds64, st) : dispatch64<1>(k, grid64, lds64, st);
     }
     const int esz = p.dtype == STL_BF16 ? 2 : 4;

@@ -765,7 +765,7 @@ class Engine:
         # chain and each stand-alone weight gradient costs its chain a full launch latency, whatever its size), every
         # block walks gsize times as many pixel tiles, and gsize times fewer split-K slabs are written and reduced.
         gsize = 1
-        if ctile == 32 and not big and os.environ.get("STLPOSE_SKIP_WGRAD", "0") == "0":
+        if (ctile == 32 or os.environ.get("STLPOSE_WGRAD_GROUP64", "1") != "0") and not big and os.environ.get("STLPOSE_SKIP_WGRAD", "0") == "0":
             gsize = max(1, min(int(os.environ.get("STLPOSE_WGRAD_GROUP", "4")), capi.WGRAD_GROUP_MAX, max(1, budget // chunks)))
         if gsize > 1:
             bg = budget // gsize
