@@ -24,6 +24,9 @@
 namespace {
 
 constexpr int PSA = 96;
+#ifndef STL_CONV_S8_CO_DEFAULT
+#define STL_CONV_S8_CO_DEFAULT ""
+#endif
 
 // debug-only phase stamps (block 0, thread 0; enabled by STL_CONV_STAMPS=1): never read by the kernel
 __device__ long long g_stamps[32];
@@ -779,14 +782,30 @@ Plan choose_plan(const stl_conv& p, int ck) {
     for (int shape = 0; shape < NSHAPES; ++shape) {
         const Shape sh = SHAPES[shape];
         if (sh.px > 128 && p.stride == 2) continue;  // stride-2 halos only fit the small blocks
-        if ((shape == 1 || shape == 5 || shape == 8) && p.Co > 32) continue;
-        if (shape == 3) continue;  // 256x128 block spills registers; reachable via STL_CONV_SHAPE only
+        // 256 px x 128 co blocks (every input pixel staged once for C = 128): spills ~30 registers; STL_CONV_S3_CO=128 tries it
+        static const int s3_co = getenv("STL_CONV_S3_CO") ? atoi(getenv("STL_CONV_S3_CO")) : 0;
+        const bool s3 = s3_co > 0 && p.Co == s3_co && p.Ci == s3_co && p.stride == 1 && p.ks == 3 && !p.stuff && !p.wg_partial;
+        if (shape == 3 && !s3) continue;
+        if (s3 && shape != 3) continue;
         // 128 px x 32 co blocks (four per CU) win in isolation for the C<=32 3x3 layers (21.7 vs 28.2 us)
         const int s4_maxco = getenv("STL_CONV_SHAPE4_MAXCO") ? atoi(getenv("STL_CONV_SHAPE4_MAXCO")) : 32;
         // ... except with many input channels on a large map (transition1: 256 -> 32 at 96x72, 8 chunks of K per tile): the
         // 512 px x 32 co block (8 waves) stages each filter chunk once per 512 pixels instead of once per 128 (105.8 -> 71.8 us)
         const bool wide_k = p.Co <= 32 && p.Ci >= 128 && p.stride == 1 && p.ks == 3 && !p.stuff && !p.wg_partial && (int64_t)p.B * p.Ho * p.Wo >= 65536;
-        const bool c32 = p.wg_partial || (!getenv("STL_CONV_NO_C32_SHAPE4") && p.Co <= s4_maxco && p.stride == 1 && p.ks == 3 && !wide_k);
+        // STL_CONV_S8_CO="128[,64]": output-channel counts above 32 that also take the 256 px x 32 co blocks (ny = Co / 32
+        // channel blocks per pixel tile; alone 24x18 C = 128 runs 14.2 us instead of 17.9 us: 232 blocks instead of 116)
+        static const char* s8_co = getenv("STL_CONV_S8_CO") ? getenv("STL_CONV_S8_CO") : STL_CONV_S8_CO_DEFAULT;
+        bool s8_extra = false;
+        {
+            char want[16];
+            snprintf(want, sizeof(want), ",%d,", p.Co);
+            char have[64];
+            snprintf(have, sizeof(have), ",%s,", s8_co);
+            s8_extra = strstr(have, want) != nullptr && p.stride == 1 && p.ks == 3 && !p.stuff && !p.wg_partial && p.Ci == p.Co &&
+                       (!getenv("STL_CONV_S8_FWD_ONLY") || p.src.mode != STL_SRC_BNBWD);
+        }
+        if ((shape == 1 || shape == 5 || (shape == 8 && !s8_extra)) && p.Co > 32) continue;
+        const bool c32 = p.wg_partial || s8_extra || (!getenv("STL_CONV_NO_C32_SHAPE4") && p.Co <= s4_maxco && p.stride == 1 && p.ks == 3 && !wide_k);
         // ... and 256 px x 32 co blocks of 8 waves (shape 8) win END TO END although they lose in isolation (C = 32 at
         // 96x72: 19.8 vs 17.9 us alone, 16.27 vs 16.47 ms per step): two 128-pixel halves share one copy of the filters
         // and one halo tile, i.e. fewer bytes per launch and half as many blocks competing for the CUs.  Shape 4 stays
