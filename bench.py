@@ -365,6 +365,11 @@ def main():
     # rehearsal of the bucketed all-reduce path, round 3: 15.39 ms per step with the collectives vs 15.44 without); with 8
     # they become queues of their own and the same step takes 23.7 ms (5 / 6 queues: 22.4 / 22.1).  Keep four.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
+    # Rank 0 prints ONE JSON line on stdout and nothing else: libraries that write banners to file descriptor 1 (RCCL prints
+    # its version block there when the communicator is created) are sent to stderr; the line goes out through the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -519,7 +524,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.arch, a.height, a.width)
             if not a.no_extras:
                 out["cpu_baseline"]["cfg1"] = cpu_baseline_cfg1()
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or pg is not None:
         torch.distributed.destroy_process_group()
 
