@@ -247,6 +247,21 @@ class Evaluator:
             import torch.distributed as dist
             self.rank, self.world = dist.get_rank(process_group), dist.get_world_size(process_group)
 
+    def _my_batches(self, loader):
+        """(global batch index, batch) pairs this rank evaluates.  One process: all of them.  shard_loader=True: batches
+        rank, rank + world, ...; an INDEXABLE loader (list of batches, a map-style dataset of batches: __len__ and
+        __getitem__) is indexed directly, so a rank never loads or decodes the batches of the others; a plain iterable
+        can only be skipped through."""
+        if self.world == 1 or not self.shard_loader:
+            yield from enumerate(loader)
+        elif hasattr(loader, "__getitem__") and hasattr(loader, "__len__"):
+            for bi in range(self.rank, len(loader), self.world):
+                yield bi, loader[bi]
+        else:
+            for bi, batch in enumerate(loader):
+                if bi % self.world == self.rank:
+                    yield bi, batch
+
     def _batch_outputs(self, imgs, target, target_weight, centers, scales):
         """network + loss + PCK + decode for one batch (the only device work of the evaluation):
         returns (loss, avg PCK, keypoints (n,17,2) in image coordinates, max_vals (n,17,1))."""
@@ -267,9 +282,7 @@ class Evaluator:
         loss_sum = acc_sum = 0.0
         nb = 0
         all_preds, all_boxes, image_ids, seq = [], [], [], []
-        for bi, (imgs, target, target_weight, metadata) in enumerate(loader):
-            if self.world > 1 and self.shard_loader and bi % self.world != self.rank:
-                continue
+        for bi, (imgs, target, target_weight, metadata) in self._my_batches(loader):
             gbi = bi if (self.world == 1 or self.shard_loader) else int(metadata.get("batch_index", bi * self.world + self.rank))
             centers, scales = np.asarray(metadata["center"], np.float64), np.asarray(metadata["scale"], np.float64)
             score = np.asarray(metadata["score"], np.float64)
