@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
             if (a_rc[i] >= 0) {
                 int iy = y0 + (a_rc[i] >> 16), ix = cb + (a_rc[i] & 0xffff), b = b0;
                 if (iy >= 0 && ix >= 0) {
-                    while (iy >= k.PI) iy -= k.PI, ++b;
+                    { const int wr_ = fdiv(iy, k.r_PI); iy -= wr_ * k.PI, b += wr_; }
                     bool ok;
                     if (p.stuff) {
                         ok = (b < p.B) && !((iy | ix) & 1) && ((iy >> 1) < p.Hi) && ((ix >> 1) < p.Wi);
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
             int oy = ey0 + (e_yx[mi] >> 16), b = eb0;
             const int c = c0 + (e_yx[mi] & 0xffff);
             if (pok) {
-                while (oy >= vpitch) oy -= vpitch, ++b;
+                { const int wr_ = fdiv(oy, k.r_vp); oy -= wr_ * vpitch, b += wr_; }
                 pok = (b < p.B) && (oy < p.Ho) && (c < p.Wo);
             }
             pokv[mi] = pok;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
                     int oy = ey0 + (e_yx[mi] >> 16), b = eb0;
                     const int c = c0 + (e_yx[mi] & 0xffff);
                     if (pok) {
-                        while (oy >= vpitch) oy -= vpitch, ++b;
+                        { const int wr_ = fdiv(oy, k.r_vp); oy -= wr_ * vpitch, b += wr_; }
                         pok = (b < p.B) && (oy < p.Ho) && (c < p.Wo);
                     }
                     const size_t pix = pok ? (((size_t)b * p.Ho + oy) * p.Wo + c) * p.Co : 0;

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
             if (g_yx[i] >= 0 && g_chok) {
                 int oy = gy0 + (g_yx[i] >> 16), b = gb0;
                 const int c = c0 + (g_yx[i] & 0xffff);
-                while (oy >= vpitch) oy -= vpitch, ++b;
+                { const int wr_ = fdiv(oy, k.r_vp); oy -= wr_ * vpitch, b += wr_; }
                 if (b < p.B && oy < p.Ho && c < p.Wo) go = ((b * p.Ho + oy) * p.Wo + c) * p.Co + co0 + g_part * KV;
             }
             const size_t off = go >= 0 ? (size_t)go : 0;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
                 int iy = hy0 + (h_rc[i] >> 16), b = hb0;
                 const int ix = cb + (h_rc[i] & 0xffff);
                 if (iy >= 0 && ix >= 0 && ix < p.Wi) {
-                    while (iy >= k.PI) iy -= k.PI, ++b;
+                    { const int wr_ = fdiv(iy, k.r_PI); iy -= wr_ * k.PI, b += wr_; }
                     if (b < p.B && iy < p.Hi) ho = ((b * p.Hi + iy) * p.Wi + ix) * p.Ci + ci0 + g_part * KV;
                 }
             }
@@ -233,12 +233,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
         }
 #pragma unroll
         for (int i = 0; i < NVH; ++i) {
-            if (h_rc[i] < 0) continue;
+            // the loaded registers are READ unconditionally (only the LDS store is predicated): a slot that is skipped
+            // as a whole leaves its load pending on that path, and the wait-count pass then drains EVERY outstanding
+            // load (the other set's too) in front of the next instruction that overwrites the register
             V16 val = rhv[S][i];
             if (io.h.mode == STL_SRC_BN) val = xform_bn<T>(val, chc + cl, chc + 32 + cl, relu_lo);
             mask16(val, (okm[S] >> (NVG + i)) & 1u);
             const int v = tid + i * NT;
-            *reinterpret_cast<V16*>(sH + (v / VPX) * PS + g_part * 16) = val;
+            if (h_rc[i] >= 0) *reinterpret_cast<V16*>(sH + (v / VPX) * PS + g_part * 16) = val;
         }
     };
 
@@ -332,6 +334,12 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
         first = false;
         t += step;
     };
+    // NOTE (round 3, from the ISA): hipcc's wait-count insertion does not realise the "two tiles in flight" intent fully.
+    // The first use of set 0's registers in the loop gets vmcnt(2) / (1) / (0) -- a full drain, the other set's younger
+    // loads included (the join of the prologue's and the back edge's pending-load orders is resolved conservatively; a
+    // four-fold unrolled loop gets the same full drain at every second tile) -- and set 1's use then needs no wait at
+    // all.  So one tile out of two is covered by a full iteration, the other by one MFMA phase.  Counted waits would
+    // need the staging loads and their waits written as inline assembly.
     while (t < k.npt) {
         body(I0);
         if (t >= k.npt) break;
@@ -452,7 +460,7 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(const WgK k) {
             if (g_yx[i] >= 0 && g_chok) {
                 int oy = gy0 + (g_yx[i] >> 16), b = gb0;
                 const int c = c0 + (g_yx[i] & 0xffff);
-                while (oy >= vpitch) oy -= vpitch, ++b;
+                { const int wr_ = fdiv(oy, k.r_vp); oy -= wr_ * vpitch, b += wr_; }
                 if (b < p.B && oy < p.Ho && c < p.Wo) g_go[i] = ((b * p.Ho + oy) * p.Wo + c) * p.Co + co0 + g_part * KV;
             }
         }
@@ -465,7 +473,7 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(const WgK k) {
                 int iy = hy0 + (h_rc[i] >> 16), b = hb0;
                 const int ix = cb + (h_rc[i] & 0xffff);
                 if (iy >= 0 && ix >= 0 && ix < p.Wi) {
-                    while (iy >= k.PI) iy -= k.PI, ++b;
+                    { const int wr_ = fdiv(iy, k.r_PI); iy -= wr_ * k.PI, b += wr_; }
                     if (b < p.B && iy < p.Hi) h_go[i] = ((b * p.Hi + iy) * p.Wi + ix) * p.Ci + ci0 + g_part * KV;
                 }
             }
