@@ -103,6 +103,19 @@ def test_planner_dry_run(monkeypatch):
     assert len(e.bns) == 292 and e.out.shape == (2, 17, 64, 48)
     ev = Engine(m.arch, m._store, 1, 64, 64, capi.F32, False)
     assert not ev.bwd_ops
+    # residual block ends formed by the consuming conv1 (STL_SRC_BNADD): at the benchmarked size the 3 inner block ends of every
+    # branch with a block-end kernel variant are eligible (24 + 24 + 21 = 69: C = 32, 64, 128); the default merges C >= 128 only
+    def merged(e):
+        return Counter(o[1].Ci for o in e.fwd_ops if o[0] == "stl_conv_forward" and o[1].src.mode == capi.SRC_BNADD)
+    eb = Engine(m.arch, m._store, 32, 384, 288, capi.BF16, True)
+    assert merged(eb) == {128: 21} and Counter(o[0] for o in eb.fwd_ops)["stl_fuse_forward"] == 136 - 21
+    monkeypatch.setenv("STLPOSE_MERGE_MINC", "0")
+    ea = Engine(m.arch, m._store, 32, 384, 288, capi.BF16, True)
+    assert merged(ea) == {32: 24, 64: 24, 128: 21} and Counter(o[0] for o in ea.fwd_ops)["stl_fuse_forward"] == 136 - 69
+    for o in ea.fwd_ops:   # the merged conv writes the sum it consumed: src_out is the tensor the fuse launch would have produced
+        if o[0] == "stl_conv_forward" and o[1].src.mode == capi.SRC_BNADD:
+            assert o[1].src_out and o[1].src.y and o[1].src_out in o[4]
+    assert len(ea.bwd_ops) == len(eb.bwd_ops)   # backward is untouched: the sums are still materialised
 
 
 def test_choose_tile_bounds():
