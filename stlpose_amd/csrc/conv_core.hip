@@ -23,6 +23,9 @@
 
 namespace {
 
+#ifndef STL_EPRE_S8
+#define STL_EPRE_S8 0   // 1: epilogue operands of the C <= 32 data gradient requested ahead of the next stage's loads at three waves per SIMD -- measured slower (one-stream step 21.10 -> 21.53 ms, step 15.09 -> 15.38): the second resident block is worth more
+#endif
 constexpr int PSA = 96;
 #ifndef STL_CONV_S8_CO_DEFAULT
 #define STL_CONV_S8_CO_DEFAULT ""
@@ -477,7 +480,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 
     // epilogue operands (addend / masks) of all MT tiles of the wave, fetched in one burst: before the MFMAs of the
     // tile's last chunk where the block owns its CU anyway (EPRE: 12 registers per tile), else at the start of the epilogue
-    constexpr bool EPRE = (OCC <= 1 && WM == 4 && WN == 2 && NTW == 2 && Q && !PE && !FW && !ZM && sizeof(T) == 2);   // fp32 would need 96 registers and spills
+        constexpr bool EPRE = ((OCC <= 1 && WM == 4 && WN == 2 && NTW == 2) || (STL_EPRE_S8 && OCC <= 3 && WM == 8 && WN == 1 && MT == 2 && NTW == 2)) &&
+                          Q && !PE && !FW && !ZM && sizeof(T) == 2;   // fp32 would need 96 registers and spills
     auto epi_fetch = [&](int vr0, int c0, bool* pokv, size_t* pixv, EpiRaw<NTW>* er) __attribute__((always_inline)) {
         const int eb0 = fdiv(vr0, k.r_vp), ey0 = vr0 - eb0 * vpitch;
 #pragma unroll
@@ -692,7 +696,7 @@ int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStrea
             if (nva <= 3) return launch<T, KS, 4, 2, 4, 4, 3, Q, PE>(k, grid, lds, st);
             break;
         case 8:   // forward (two register sets of staged loads): three waves per SIMD, no spills
-            if (nva <= 3 && k.wres) return launch<T, KS, 8, 1, 2, 2, 3, Q, PE, 4, 1>(k, grid, lds, st);
+            if (nva <= 3 && k.wres) return launch<T, KS, 8, 1, 2, 2, 3, Q, PE, ((Q && STL_EPRE_S8) ? 3 : 4), 1>(k, grid, lds, st);
             if (nva <= 3) return launch<T, KS, 8, 1, 2, 2, 3, Q, PE, (Q ? 3 : 4)>(k, grid, lds, st);
             break;
         case 4:
