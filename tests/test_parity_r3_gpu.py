@@ -230,3 +230,40 @@ def test_vgg19_style_cfg4_shape_16x512x512_vs_oracle():
         assert abs(tot.item() - (rc + 1e3 * rs)) <= tol * abs(rc + 1e3 * rs)
         del m
         torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------ W48 at the cfg3 resolution
+def test_w48_384x288_fp32_train_step_vs_oracle():
+    """BASELINE configs[2]'s network and resolution (W48, 384 x 288; batch 4 so that the oracle runs in seconds) on the fp32
+    path against the oracle: the 48 / 96 / 192 / 384 widths at full-size maps go through the ragged channel chunks of the
+    grouped weight gradient and, for C = 192, through the block-end source (STL_SRC_BNADD) -- output 1e-3, argmax bit-exact,
+    every gradient norm 5e-3, direction 0.9995."""
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    img, tgt, tw = synth_batch(4, 384, 288, seed=4848, sigma=3.0)
+    ref = hrnet_ref.load_synth(hrnet_ref.RefPoseNet("w48")).train()
+    ro = ref(torch.from_numpy(img))
+    rl = pose_ref.person_mse_loss(ro, torch.from_numpy(tgt), torch.from_numpy(tw))
+    rl.backward()
+    m = _load_synth(PoseHighResolutionNet("w48", "fp32")).cuda().train()
+    out = m(torch.from_numpy(img).cuda())
+    loss = PersonMSELoss()(out, torch.from_numpy(tgt).cuda(), torch.from_numpy(tw).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    o, r = out.detach().cpu().numpy(), ro.detach().numpy()
+    assert np.abs(o - r).max() / np.abs(r).max() < 1e-3
+    p, _ = get_max_preds_hrnet(o)
+    pr, _ = pose_ref.get_max_preds(r)
+    assert np.array_equal(p, pr), "heatmap argmax differs from the oracle"
+    assert abs(loss.item() - rl.item()) < 1e-3 * abs(rl.item())
+    worst_n, worst_c = 0.0, 1.0
+    for (k, prm), (kr, pr_) in zip(m.named_parameters(), ref.named_parameters()):
+        assert k == kr
+        g, gr = prm.grad.detach().cpu().double().reshape(-1), pr_.grad.double().reshape(-1)
+        worst_n = max(worst_n, abs(float(g.norm()) - float(gr.norm())) / (float(gr.norm()) + 1e-30))
+        worst_c = min(worst_c, float(torch.dot(g, gr) / (g.norm() * gr.norm() + 1e-30)))
+    assert worst_n < 5e-3 and worst_c > 0.9995, (worst_n, worst_c)
+    # the plan of this run did use the block-end source for the 192-channel branch
+    from stlpose_amd import capi
+    eng = m.engine(4, 384, 288, True)
+    merged = {o_[1].Ci for o_ in eng.fwd_ops if o_[0] == "stl_conv_forward" and o_[1].src.mode == capi.SRC_BNADD}
+    assert 192 in merged, merged
