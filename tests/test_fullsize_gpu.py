@@ -110,6 +110,33 @@ def test_gradient_buckets_cover_the_flat_buffer_and_dp_path_matches(monkeypatch,
         dist.destroy_process_group()
 
 
+def test_bf16_gradient_buckets_on_a_one_rank_rccl_group(monkeypatch):
+    """bf16 gradient buckets through the real overlapped path on a one-rank RCCL communicator: the
+    collective moves bf16 copies, the fp32 gradient buffer receives them back -- every gradient within bf16 rounding
+    (2^-8 of its own magnitude) of the fp32-bucket run, the optimiser's factor is 1 (the buckets carry the mean)."""
+    import torch.distributed as dist
+    monkeypatch.setenv("STLPOSE_DP_FORCE", "1")
+    img, tgt, tw = _batch(4, 256, 192, seed=7)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29578", rank=0, world_size=1)
+    try:
+        res = []
+        for bf16 in (False, True):
+            torch.manual_seed(11)
+            m = PoseHighResolutionNet("w32", "bf16").cuda()
+            ts = TrainStep(m, 4, 256, 192, optimizer="sgd", lr=0.0, momentum=0.0, process_group=dist.group.WORLD, bf16_buckets=bf16)
+            ts.load_batch(img.cuda(), tgt.cuda(), tw.cuda())
+            ts.step()
+            torch.cuda.synchronize()
+            res.append((ts.store.grads.clone(), float(ts.hyper[7].item()), ts.dp.bf16))
+        (g32, s32, b32), (g16, s16, b16) = res
+        assert (b32, b16) == (False, True) and s32 == 1.0 and s16 == 1.0     # world 1: 1 / world = 1 either way
+        assert not torch.equal(g32, g16)                                      # the bf16 round trip did happen
+        assert float(((g16 - g32).abs() - g32.abs() * 2.0 ** -8).max()) <= 1e-12
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 def test_fused_backward_matches_separate_launches_at_full_size(monkeypatch, dt):
     """The opt-in fused backward (STLPOSE_FUSED_BWD=1) against the default stand-alone launches on the benchmarked
