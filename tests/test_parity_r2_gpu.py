@@ -54,8 +54,15 @@ def oracle_b32():
     grads = {k: p.grad.clone() for k, p in ref.named_parameters()}
     bufs = {k: v.clone() for k, v in ref.named_buffers()}
     o = out.detach().numpy()
+    # the same forward under bf16-STORAGE emulation (round 3): calibrates the bf16 path's output bar on this very batch.
+    # BatchNorm buffers were already updated by the pass above; momentum 0 keeps them as they are.
+    for mod in ref.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.momentum = 0.0
+    with torch.no_grad(), hrnet_ref.bf16_storage(ref):
+        o_emul = ref(torch.from_numpy(img)).numpy()
     del ref, out
-    return dict(img=img, tgt=tgt, tw=tw, out=o, loss=float(loss.item()), grads=grads, bufs=bufs)
+    return dict(img=img, tgt=tgt, tw=tw, out=o, out_emul=o_emul, loss=float(loss.item()), grads=grads, bufs=bufs)
 
 
 def test_w32_b32_fp32_train_step_vs_oracle(oracle_b32):
@@ -113,8 +120,11 @@ def test_w32_b32_bf16_gate_vs_oracle(oracle_b32):
     """bf16 storage / fp32 accumulate on the benchmarked batch, SURVEY section 7 gate: output within TOL of the
     fp32 oracle; argmax equal wherever the oracle's top-2 margin exceeds 2 x TOL x |out|max (a flip below that
     margin is a near-tie, not an error); PCK(accuracy) equal; gradient norms per top-level module within 10 %."""
-    TOL = 5e-2
     r = oracle_b32
+    # bar = 1.5 x what bf16 storage costs the ORACLE on this batch (oracle.hrnet_ref.bf16_storage; round 2 used a free 5e-2
+    # that the path met with 2 % headroom -- the emulation shows that figure IS the storage format's: ~5e-2 on random weights)
+    err_emul = float(np.abs(r["out_emul"] - r["out"]).max() / np.abs(r["out"]).max())
+    TOL = 1.5 * err_emul + 1e-3
     m = _load_synth(PoseHighResolutionNet("w32", "bf16")).cuda().train()
     out = m(torch.from_numpy(r["img"]).cuda())
     loss = PersonMSELoss()(out, torch.from_numpy(r["tgt"]).cuda(), torch.from_numpy(r["tw"]).cuda())
@@ -138,7 +148,7 @@ def test_w32_b32_bf16_gate_vs_oracle(oracle_b32):
         top = k.split(".")[0]
         gn[top] = gn.get(top, 0.0) + float((prm.grad.double() ** 2).sum())
         gnr[top] = gnr.get(top, 0.0) + float((r["grads"][k].double() ** 2).sum())
-    _diag("diag_w32_b32_bf16.txt", [f"out rel err {err:.3e} (bar {TOL})", f"loss {loss.item()} ref {r['loss']}",
+    _diag("diag_w32_b32_bf16.txt", [f"out rel err {err:.3e} (bf16-storage emulation of the oracle {err_emul:.3e}, bar {TOL:.3e})", f"loss {loss.item()} ref {r['loss']}",
                                     f"argmax: {int(same.sum())}/{same.size} equal, {int((~same).sum())} flipped; decisive maps {int(decisive.sum())}, flipped among them {int((decisive & ~same).sum())}",
                                     f"smallest margin among flipped / |out|max: {float(margin[~same].max() / absmax) if (~same).any() else 0.0:.3e}",
                                     f"PCK bf16 {acc_b[1]:.6f} oracle {acc_r[1]:.6f} device accuracy() {acc_dev[1]:.6f}",
