@@ -141,8 +141,18 @@ def test_w32_bf16_close_to_fp32_reference(golden_dir):
     vals = np.array([np.sqrt(gn[k]) for k in g["gradnorm_keys"]])
     _diag("diag_w32_bf16.txt", [f"out rel err {err:.3e}", f"argmax agreement {agree:.3f}", f"loss {loss.item()} ref {float(g['loss'])}",
                                 "gradnorm " + " ".join(f"{k}:{v:.4e}/{r:.4e}" for k, v, r in zip(g["gradnorm_keys"], vals, g["gradnorm_vals"]))])
-    assert err < 5e-2
-    assert agree >= 0.8   # random-weight heatmaps have near-ties; bf16 storage flips some of them
+    # Calibration (round 3): the fp32 oracle re-run with bf16 rounding at the HIP path's storage points.  The bars are that
+    # run's own distance from the reference fixture (x 1.5 for the output, - 10 % of the maps for the argmax), not free constants.
+    from oracle import hrnet_ref
+    ref = hrnet_ref.load_synth(hrnet_ref.RefPoseNet("w32")).train()
+    with torch.no_grad(), hrnet_ref.bf16_storage(ref):
+        oe = ref(torch.from_numpy(img)).numpy()
+    err_emul = np.abs(oe.reshape(-1)[::64] - g["out_sample"]).max() / float(g["out_absmax"])
+    pe, _ = get_max_preds_hrnet(oe)
+    agree_emul = float((pe == g["argmax_xy"]).all(-1).mean())
+    _diag("diag_w32_bf16_emulation.txt", [f"emulation: out rel err {err_emul:.3e}, argmax agreement {agree_emul:.3f}; HIP bf16: {err:.3e}, {agree:.3f}"])
+    assert err < 1.5 * err_emul + 1e-3, (err, err_emul)
+    assert agree >= agree_emul - 0.1, (agree, agree_emul)   # random-weight heat maps have near-ties; bf16 storage flips some of them
     assert abs(loss.item() - float(g["loss"])) < 2e-2 * float(g["loss"])
     np.testing.assert_allclose(vals, g["gradnorm_vals"], rtol=0.1)
 
