@@ -170,6 +170,7 @@ class Engine:
         self.wgrad_streams = wgs not in ("0", "auto")
         self.nwstreams = 0 if not self.wgrad_streams else (int(wgs[1:]) if wgs.startswith("n") else self.nstreams)
         self._stream = 0
+        self._fwd_streams = max(1, min(self.nstreams, int(os.environ.get("STLPOSE_FWD_STREAMS", str(self.nstreams)))))   # streams of the FORWARD program only
         self._side = None
         self._chain_mask = bool(os.environ.get("STLPOSE_CUMASK_CHAIN", ""))
         self._stats_used = 0
@@ -180,6 +181,8 @@ class Engine:
         self._build_tables()
         if training:
             self._build_backward()
+        if os.environ.get("STLPOSE_ISSUE_ORDER", "0") != "0":
+            self.fwd_ops = self._issue_order(self.fwd_ops)
 
     # ------------------------------------------------------------------ allocation helpers
     def _alloc(self, nbytes: int) -> torch.Tensor:
@@ -282,7 +285,7 @@ class Engine:
         p.grid_pct = self._grid_pct(ck)
         reads, writes = [x.ptr], [y.ptr]
         pend = x.pending
-        if (pend is not None and self.merge_block_end and kks == 3 and kstride == 1 and pend[0][2] == self._stream
+        if (pend is not None and self.merge_block_end and kks == 3 and kstride == 1 and pend[0][2] == self._stream % self._fwd_streams
                 and int(os.environ.get("STLPOSE_MERGE_MINC", "128")) <= x.C <= int(os.environ.get("STLPOSE_MERGE_MAXC", "4096"))
                 and capi.lib().stl_conv_bnadd_ok(C.byref(p)) == 1):
             # Residual block end z = ReLU(BN(y2) + skip) whose FIRST consumer is this 3x3 convolution (the next unit's
@@ -302,7 +305,7 @@ class Engine:
         if self.training:
             p.out_stats = self.stats.data_ptr() + 8 * bn.stats_off
         self._wk_fix.append((p, "w", ci.fwd_off))
-        self.fwd_ops.append(("stl_conv_forward", p, self._stream, reads, writes))
+        self.fwd_ops.append(("stl_conv_forward", p, self._stream % self._fwd_streams, reads, writes))
         x.consumers += 1
         self.tape.append(("conv", x, y, ci, (kks, kstride), self._stream))
         return y
@@ -323,7 +326,7 @@ class Engine:
             p.t[i].shift = s
             a.consumers += 1
         p.out = z.ptr
-        op = ("stl_fuse_forward", p, self._stream, [a.ptr for a, _, _ in terms], [z.ptr])
+        op = ("stl_fuse_forward", p, self._stream % self._fwd_streams, [a.ptr for a, _, _ in terms], [z.ptr])
         self.fwd_ops.append(op)
         self.tape.append(("fuse", terms, z, relu, self._stream))
         if relu and len(terms) == 2 and all(s == 0 for _, s, _ in terms):
@@ -419,6 +422,11 @@ class Engine:
             bk["lo"] = min(bk["lo"], off)
 
         self._wg_pending: Dict[Tuple, List] = {}   # grouped weight gradients waiting for their group to fill
+        # STLPOSE_WGRAD_DEFER=1: a full group is not issued where it fills (in the middle of its branch's data-gradient chain,
+        # on that chain's own stream) but when the reverse walk leaves the branch: the chain reaches the exchange earlier and the
+        # weight gradients run beside the exchange's small launches
+        self._wg_ready: List[Tuple] = []
+        self._wg_defer = os.environ.get("STLPOSE_WGRAD_DEFER", "0") != "0"
         # how many layers share each weight-gradient shape.  STLPOSE_WGRAD_COUNT=1 sizes a shape's groups by it, so that a shape
         # which occurs once (transition convs, the stem) gets the whole block budget instead of a quarter -- measured 0.04-0.06 ms
         # per step SLOWER (15.17 / 15.13 / 15.12 vs 15.11 / 15.09 / 15.07): these launches run beside the data-gradient chain of the
@@ -436,8 +444,9 @@ class Engine:
             if not complete or bk["done"] == 0 or (bk["done"] < bucket_min and not force):
                 return
             assert complete
+            self._flush_ready_groups(ops)
             for key in list(self._wg_pending):                     # the bucket's slab reduction reads every member's slabs
-                self._flush_wgrad_group(ops, key)
+                self._flush_wgrad_group(ops, key, now=True)
             rr, br = capi.ReduceRange(), capi.BNRange()
             b = dict(lo=bk["lo"], hi=bk["hi"], slab0=bk["slab0"], slab1=len(self.slabs), rr=rr, br=br)
             wstrm = bk["strm"]
@@ -526,6 +535,8 @@ class Engine:
                 _, x, y, ci, (kks, kstride), strm = node
                 x.bwd_seen += 1
                 assert y.consumers == 1 and y.dt is not None, f"{ci.key}: BN activation must have exactly one consumer"
+                if self._wg_ready and self._wg_ready[0][0][:6] != (x.C, y.C, kks, kstride, x.H, x.W):
+                    self._flush_ready_groups(ops)      # the walk has left the branch whose groups are waiting
                 g = self._gsrc(y)
                 wstrm = (self.nstreams + strm % self.nwstreams) if self.wgrad_streams else strm
                 # Fused backward (conv_core.hip, NCO > 0): the two-conv units' 3x3 stride-1 C -> C convolutions with
@@ -635,6 +646,8 @@ class Engine:
             br.tab, br.n = self._bn_tab.data_ptr() + i0 * C.sizeof(capi.BNRec), i1 - i0
         ops = self._lag_wgrads(ops, int(os.environ.get("STLPOSE_WGRAD_LAG", "0")))
         self.bwd_ops = self._balance_streams(ops) if self.wgrad_auto else ops
+        if os.environ.get("STLPOSE_ISSUE_ORDER", "0") != "0":
+            self.bwd_ops = self._issue_order(self.bwd_ops)
         for b in self.buckets:   # bucket events are addressed by op index
             b["op"] = next(i for i, o in enumerate(self.bwd_ops) if o[1] is b["br"])
 
@@ -800,7 +813,16 @@ class Engine:
         if len(pend) >= gsize:
             self._flush_wgrad_group(ops, key)
 
-    def _flush_wgrad_group(self, ops, key):
+    def _flush_ready_groups(self, ops):
+        ready, self._wg_ready = self._wg_ready, []
+        for key, pend in ready:
+            self._wg_pending[key] = pend
+            self._flush_wgrad_group(ops, key, now=True)
+
+    def _flush_wgrad_group(self, ops, key, now: bool = False):
+        if self._wg_defer and not now:
+            self._wg_ready.append((key, self._wg_pending.pop(key)))
+            return
         pend = self._wg_pending.pop(key, [])
         if not pend:
             return
@@ -859,6 +881,38 @@ class Engine:
                 last[t] = i
         need.update(b["op"] for b in getattr(self, "buckets", []) if ops is self.bwd_ops)
         return waits, need
+
+    def _issue_order(self, ops):
+        """Host issue order = the order in which the launches can START on the device: an in-order replay of the plan's
+        streams with estimated durations (dependencies as in _schedule), launches sorted by their simulated start time.
+        The planner emits a module's branches one after the other (forward: branch 0 first; backward: branch 3 first), so
+        a host that is not far ahead of the device feeds one queue while the others wait for their first launch of the
+        module.  Per-stream order and every read-after-write dependency are preserved (tensors are written once per pass)."""
+        last, sfin, fin, start = {}, {}, [], []
+        for i, op in enumerate(ops):
+            name, desc, st_, reads, writes = op
+            t0 = sfin.get(st_, 0.0)
+            for r in reads:
+                j = last.get(r)
+                if j is not None:
+                    t0 = max(t0, fin[j])
+            d = self._op_cost_us(op) if name != "stl_conv_forward" or True else 0.0
+            start.append(t0)
+            fin.append(t0 + d)
+            sfin[st_] = t0 + d
+            for w in writes:
+                last[w] = i
+        order = sorted(range(len(ops)), key=lambda i: (start[i], i))
+        # safety: a dependency must never be issued after its consumer
+        pos = {i: k for k, i in enumerate(order)}
+        last = {}
+        for i, (_, _, st_, reads, writes) in enumerate(ops):
+            for r in reads:
+                j = last.get(r)
+                assert j is None or pos[j] < pos[i], "issue order breaks a dependency"
+            for w in writes:
+                last[w] = i
+        return [ops[i] for i in order]
 
     def _program(self, ops):
         """Compile an op list into a native program (csrc/program.hip), once."""
