@@ -58,11 +58,35 @@ struct ConvK {
     int TH, TW;
     int dbg;
     float r_HC, r_TW, r_tc, r_PI, r_vp;  // reciprocals for fdiv
+    unsigned long long m_tc, m_PI, m_vp;  // ceil(2^32 / d): uniform n / d = (n * m) >> 32 on the scalar unit (sdiv)
     int ny;  // output-channel blocks per pixel tile (they are the FAST block dimension, see kernel)
     // fused weight gradient (p.wg_partial != NULL): LDS offsets of the h-slab halo tile / its BN constants,
     // bytes per h pixel, K steps (of 4*KV pixels) that cover the pixel tile
     int off_h, off_ch, psh, nks;
 };
+
+// Integer multiplies: v_mul_lo_u32 and v_mad_u64_u32 are quarter rate (16 cycles a wave), the 24-bit forms full rate.
+// Element offsets are therefore built with 24-bit mads (tensors of up to 2^24 pixels and 2^31 elements: checked on the
+// host) and the tile-uniform terms with integer arithmetic on the scalar unit.  Inline asm keeps the mads out of reach
+// of LLVM's 64-bit mad combine.
+__device__ __forceinline__ int mad24_vsv(int a, int b_uniform, int c) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+    return r;
+}
+// a * b + c, a and b unsigned 24-bit (bits 24-31 ignored), b uniform
+__device__ __forceinline__ int madu24_vsv(int a, int b_uniform, int c) {
+    int r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int mulu24_vs(int a, int b_uniform) {
+    int r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(b_uniform), "v"(a));
+    return r;
+}
+// n / d for uniform n >= 0 with m = ceil(2^32 / d) (exact for n * d < 2^32): integer only, so it stays on the scalar unit
+__device__ __forceinline__ int sdiv(int n, unsigned long long m) { return (int)(((unsigned long long)(uint32_t)n * m) >> 32); }
 
 // transposed LDS fragment reads for the fused weight gradient (K = pixels; same forms as wgrad.hip)
 template <typename T>
@@ -156,7 +180,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     // neighbours, so they run at the same time on the same L2: the input tile is fetched from HBM
     // once for all of them, and the ny pieces of every output row are written together.
     const int bl = blockIdx.x >> 3;
-    const int by = bl % k.ny, lx = bl / k.ny;
+    const int lx = __builtin_amdgcn_readfirstlane(bl / k.ny), by = bl - lx * k.ny;   // (the division runs on the vector unit: back to scalars)
     const int n0 = by * BCO;
     const bool wres = WR < 0 ? (k.wres != 0) : (WR == 1);
 
@@ -273,26 +297,24 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     bool st_have[NSET];
 
     auto tile_setup = [&](int t, int* go) {
-        const int tr = fdiv(t, k.r_tc), tc = t - tr * k.tiles_c;
+        const int tr = sdiv(t, k.m_tc), tc = t - tr * k.tiles_c;
         const int vrs = tr * k.TH * k.seff, cb = tc * k.TW * k.seff - k.pad;
-        const int b0 = fdiv(vrs, k.r_PI), y0 = vrs - b0 * k.PI - k.pad;
+        const int b0 = sdiv(vrs, k.m_PI), y0 = vrs - b0 * k.PI - k.pad;
+        const int n_PI = -k.PI;
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
-            go[i] = -1;
-            if (a_rc[i] >= 0) {
-                int iy = y0 + (a_rc[i] >> 16), ix = cb + (a_rc[i] & 0xffff), b = b0;
-                if (iy >= 0 && ix >= 0) {
-                    { const int wr_ = fdiv(iy, k.r_PI); iy -= wr_ * k.PI, b += wr_; }
-                    bool ok;
-                    if (p.stuff) {
-                        ok = (b < p.B) && !((iy | ix) & 1) && ((iy >> 1) < p.Hi) && ((ix >> 1) < p.Wi);
-                        iy >>= 1, ix >>= 1;
-                    } else {
-                        ok = (b < p.B) && (iy < p.Hi) && (ix < p.Wi);
-                    }
-                    if (ok) go[i] = ((b * p.Hi + iy) * p.Wi + ix) * p.Ci + a_part * KV;
-                }
+            const int iy0 = y0 + (a_rc[i] >> 16);
+            int ix = cb + (a_rc[i] & 0xffff);
+            const int wr_ = fdiv(iy0 < 0 ? 0 : iy0, k.r_PI);
+            int iy = mad24_vsv(wr_, n_PI, iy0);
+            bool ok = (a_rc[i] >= 0) & (iy0 >= 0) & (ix >= 0) & (b0 + wr_ < p.B);
+            if (p.stuff) {   // zero-stuffed source (transposed convolution): only even rows / columns exist
+                ok = ok & !((iy | ix) & 1);
+                iy >>= 1, ix >>= 1;
             }
+            ok = ok & (iy < p.Hi) & (ix < p.Wi);
+            const int e = madu24_vsv(madu24_vsv(madu24_vsv(b0 + wr_, p.Hi, iy), p.Wi, ix), p.Ci, a_part * KV);
+            go[i] = ok ? e : -1;
         }
     };
     // Loads are UNCONDITIONAL (invalid slots read element 0 and are zeroed at write time): a
@@ -304,8 +326,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
             const int off = (go[i] >= 0 && chok) ? go[i] + k0 : 0;
-            ra[S][i] = ldg16((const char*)p.src.x + (size_t)off * sizeof(T));
-            if (Q) rq[S][i] = ldg16((const char*)p.src.y + (size_t)off * sizeof(T));
+            ra[S][i] = ldg16((const char*)p.src.x + (size_t)(uint32_t)off * sizeof(T));
+            if (Q) rq[S][i] = ldg16((const char*)p.src.y + (size_t)(uint32_t)off * sizeof(T));
             if constexpr (FW) {   // h slab of the same halo pixel (Ci == Co): only with the first chunk of a tile
                 const int hoff = (go[i] >= 0 && en && k0 == 0) ? go[i] + n0 : 0;
 #pragma unroll
@@ -380,7 +402,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 #pragma unroll
         for (int h = 0; h < 2; ++h) s0[ni][h] = f2v{0.f, 0.f}, s1[ni][h] = f2v{0.f, 0.f};
 
-    const int xcd = blockIdx.x & 7, nx = (gridDim.x >> 3) / k.ny;
+    const int xcd = blockIdx.x & 7, nx = __builtin_amdgcn_readfirstlane((gridDim.x >> 3) / k.ny);
     const int T8 = (k.npt + 7) >> 3;
     const int vpitch = p.Ho + 1;
 
@@ -482,20 +504,22 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     // tile's last chunk where the block owns its CU anyway (EPRE: 12 registers per tile), else at the start of the epilogue
         constexpr bool EPRE = ((OCC <= 1 && WM == 4 && WN == 2 && NTW == 2) || (STL_EPRE_S8 && OCC <= 3 && WM == 8 && WN == 1 && MT == 2 && NTW == 2)) &&
                           Q && !PE && !FW && !ZM && sizeof(T) == 2;   // fp32 would need 96 registers and spills
+    // element index (times Co) of this lane's output pixel in pixel tile mi of the tile at (vr0, c0); pok = inside the image
+    auto out_pixel = [&](int vr0, int c0, int mi, bool& pok) __attribute__((always_inline)) -> size_t {
+        const int eb0 = sdiv(vr0, k.m_vp), ey0 = vr0 - eb0 * vpitch;
+        const int ty = e_yx[mi] >> 16, tx = e_yx[mi] & 0xffff;
+        const int oy0 = ey0 + ty, c = c0 + tx;
+        const int wr_ = fdiv(oy0, k.r_vp);
+        const int oy = mad24_vsv(wr_, -vpitch, oy0), b = eb0 + wr_;
+        pok = (e_yx[mi] >= 0) & (b < p.B) & (oy < p.Ho) & (c < p.Wo);
+        const int e = mulu24_vs(madu24_vsv(madu24_vsv(b, p.Ho, oy), p.Wo, c), p.Co);
+        return pok ? (size_t)(uint32_t)e : 0;
+    };
     auto epi_fetch = [&](int vr0, int c0, bool* pokv, size_t* pixv, EpiRaw<NTW>* er) __attribute__((always_inline)) {
-        const int eb0 = fdiv(vr0, k.r_vp), ey0 = vr0 - eb0 * vpitch;
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
-            bool pok = e_yx[mi] >= 0;
-            int oy = ey0 + (e_yx[mi] >> 16), b = eb0;
-            const int c = c0 + (e_yx[mi] & 0xffff);
-            if (pok) {
-                { const int wr_ = fdiv(oy, k.r_vp); oy -= wr_ * vpitch, b += wr_; }
-                pok = (b < p.B) && (oy < p.Ho) && (c < p.Wo);
-            }
-            pokv[mi] = pok;
-            pixv[mi] = pok ? (((size_t)b * p.Ho + oy) * p.Wo + c) * p.Co : 0;
-            epilogue_fetch<T, NTW, true>(p, pok, pixv[mi], n0, wn * NTW * 16, g, er[mi]);
+            pixv[mi] = out_pixel(vr0, c0, mi, pokv[mi]);
+            epilogue_fetch<T, NTW, true>(p, pokv[mi], pixv[mi], n0, wn * NTW * 16, g, er[mi]);
         }
     };
 
@@ -504,7 +528,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     auto stage = [&](auto SET) __attribute__((always_inline)) {
         constexpr int S = decltype(SET)::value;
         const int t = st_t[S], ch0 = st_ch[S];
-        const int tr = fdiv(t, k.r_tc), tc = t - tr * k.tiles_c;
+        const int tr = sdiv(t, k.m_tc), tc = t - tr * k.tiles_c;
         const int vr0 = tr * k.TH, c0 = tc * k.TW;
         write_lds(SET, a_go[S], ch0 * CK);
         __syncthreads();
@@ -560,17 +584,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
                 for (int mi = 0; mi < MT; ++mi)
                     epilogue_apply<T, NTW, BCO>(p, acc[mi], cm, pokv[mi], pixv[mi], n0, wn * NTW * 16, g, s0, s1, er[mi]);
             } else {   // register-tight instantiations: tile by tile
-                const int eb0 = fdiv(vr0, k.r_vp), ey0 = vr0 - eb0 * vpitch;
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) {
-                    bool pok = e_yx[mi] >= 0;
-                    int oy = ey0 + (e_yx[mi] >> 16), b = eb0;
-                    const int c = c0 + (e_yx[mi] & 0xffff);
-                    if (pok) {
-                        { const int wr_ = fdiv(oy, k.r_vp); oy -= wr_ * vpitch, b += wr_; }
-                        pok = (b < p.B) && (oy < p.Ho) && (c < p.Wo);
-                    }
-                    const size_t pix = pok ? (((size_t)b * p.Ho + oy) * p.Wo + c) * p.Co : 0;
+                    bool pok;
+                    const size_t pix = out_pixel(vr0, c0, mi, pok);
                     epilogue_tile<T, NTW, BCO, PE>(p, acc[mi], cm, pok, pix, n0, wn * NTW * 16, g, s0, s1);
                 }
             }
@@ -983,6 +1000,14 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     k.npt = ceil_div(vrows, plan.TH) * k.tiles_c;
     k.r_HC = 1.0f / k.HC, k.r_TW = 1.0f / k.TW, k.r_tc = 1.0f / k.tiles_c, k.r_PI = 1.0f / k.PI, k.r_vp = 1.0f / (p.Ho + 1);
     STL_CHECK(k.npt < (1 << 21) && (int64_t)vrows * 2 < (1 << 21) && k.HP < 4096, "conv: index range exceeds the fast-division limits");
+    STL_CHECK(k.tiles_c < (1 << 11) && k.PI < (1 << 11) && p.Ho + 1 < (1 << 11), "conv: rows / columns exceed the scalar-division limits (2047)");
+    {
+        const unsigned long long two32 = 1ull << 32;
+        k.m_tc = (two32 + k.tiles_c - 1) / k.tiles_c, k.m_PI = (two32 + k.PI - 1) / k.PI, k.m_vp = (two32 + p.Ho) / (p.Ho + 1);
+    }
+    STL_CHECK((int64_t)p.B * p.Hi * p.Wi < (1 << 24) && (int64_t)p.B * p.Ho * p.Wo < (1 << 24) && (int64_t)p.B * p.Hi * p.Wi * p.Ci < ((int64_t)1 << 31) &&
+                  (int64_t)p.B * p.Ho * p.Wo * p.Co < ((int64_t)1 << 31),
+              "conv: tensors beyond 2^24 pixels or 2^31 elements are not addressable (24-bit multiplies, 32-bit element offsets)");
     const Shape sh = SHAPES[plan.shape];
     int gx = ceil_div(k.npt, 8) * 8;
     // resident waves per SIMD ~2: persistent blocks that loop over their tiles with the next tile's

@@ -26,6 +26,17 @@ __device__ long long g_wstamps[16];
 #define WSTAMP(i) do {} while (0)
 #endif
 
+// a * b + c with 24-bit a, b (b uniform): full rate, and kept out of reach of the 64-bit mad combine
+__device__ __forceinline__ int mad24_vsv(int a, int b_uniform, int c) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+    return r;
+}
+
+// n / d for uniform n >= 0 with m = ceil(2^32 / d): integer only, so it stays on the scalar unit (fdiv's conversions are
+// vector instructions, and everything computed from their result would be vector arithmetic too)
+__device__ __forceinline__ int sdiv(int n, unsigned long long m) { return (int)(((unsigned long long)(uint32_t)n * m) >> 32); }
+
 constexpr int WG_MAXG = STL_WGRAD_GROUP_MAX;
 struct WgK {
     stl_wgrad p;           // problem 0 (geometry, tile, nsplit: shared by every member of a group)
@@ -36,6 +47,7 @@ struct WgK {
     int psg, psh;  // LDS bytes per pixel (32 channels + 16 B pad)
     int off_cg, off_ch, off_g, off_h;
     float r_TW, r_HC, r_tc, r_vp, r_PI;  // reciprocals for fdiv
+    unsigned long long m_tc, m_vp, m_PI;  // ceil(2^32 / d): exact n / d = (n * m) >> 32 on the scalar unit for n * d < 2^32
 };
 
 
@@ -362,6 +374,275 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
     WSTAMP(8);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised variant (round 3): 8 waves, waves 4-7 LOAD (global -> registers -> BatchNorm(+ReLU) / BatchNorm-backward
+// transform -> LDS), waves 0-3 MULTIPLY (one 16 x 16 quadrant of the block's 32 x 32 channels each, ALL taps), through a
+// double-buffered LDS image with ONE barrier per tile: while the compute waves read tile i out of buffer i & 1 the
+// loaders transform and write tile i + 1 into the other buffer.  In the uniform kernel above the same eight waves do
+// staging, LDS write, fragment reads and MFMAs phase by phase between two barriers (a tile takes 1.67 us of a CU whatever
+// the occupancy, although no single pipe needs more than half of that); here each SIMD hosts one loader and one compute
+// wave, so the vector / LDS-write work of tile i + 1 runs beside the matrix / LDS-read work of tile i.
+// Loader threads keep TWO register sets of loads in flight (tiles i + 1 and i + 2).
+#ifndef WS_WPE
+#define WS_WPE 2   // waves per SIMD of the register budget: 2 = one block per CU (134 VGPRs; 4 = two blocks, 128 VGPRs, spills in the tile loop: 76 vs 41 us)
+#endif
+template <typename T, int KS, int NVH, bool GQ>
+__global__ __launch_bounds__(512, WS_WPE) void wgrad_ws_kernel(const WgK k) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KV = ET<T>::KV, TAPS = KS * KS, TPX = 128;
+    constexpr int KSTEP = 4 * KV;
+    constexpr int NR = sizeof(T) == 2 ? 2 : 4;
+    constexpr int VPX = 32 / KV;
+    constexpr int NL = 256;                       // loader threads
+    constexpr int NVG = TPX * VPX / NL;           // g staging vectors per loader thread (2 bf16 / 4 fp32)
+    constexpr int PS = 32 * (int)sizeof(T) + 16;
+    constexpr int NKT = TPX / KSTEP;
+    const stl_wgrad& p = k.p;
+    const int member = __builtin_amdgcn_readfirstlane(blockIdx.x / p.nsplit);   // the division runs on the vector unit: back to scalars,
+    const int bsplit = blockIdx.x - member * p.nsplit;                           // or every tile term below stays vector arithmetic
+    const stl_wgrad_io& io = k.io[member];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
+    const int co0 = blockIdx.y * 32, ci0 = blockIdx.z * 32;
+    float* cgc = reinterpret_cast<float*>(smem + k.off_cg);  // [3][32]
+    float* chc = reinterpret_cast<float*>(smem + k.off_ch);  // [2][32]
+    const int bufsz = k.off_h - k.off_g + k.HP * PS;          // one LDS image: g tile + h halo tile
+    const int tilepx = p.TH * p.TW;
+    const int vpitch = p.Ho + 1;
+    const int hrow = k.HC * PS;
+    const int step = p.nsplit;
+    const int ntile = bsplit < k.npt ? (k.npt - bsplit + step - 1) / step : 0;   // tiles of this block (block-uniform)
+
+    if (loader) {
+        const int ltid = tid - NL;
+        // ---- constants (wave 7: lanes 0-31 those of g, 32-63 those of h), loads issued ahead of the first tiles' loads
+        SrcRaw raw;
+        const bool cw = wave == 7, cg = lane < 32;
+        const int cch = lane & 31;
+        const bool cok = cw && (cg ? co0 + cch < p.Co : ci0 + cch < p.Ci);
+        if (cok) {
+            if (cg) src_raw_load(io.g, co0 + cch, p.Co, raw);
+            else src_raw_load(io.h, ci0 + cch, p.Ci, raw);
+        }
+        // ---- loop-invariant staging descriptors.  Everything a slot needs per tile is straight-line arithmetic on
+        // these (no divergent branches: with one loader wave per SIMD nothing hides a branch bubble or an LDS wait).
+        int g_ty[NVG], g_tx[NVG];
+        const int g_part = ltid % VPX;
+        const bool g_chok = (co0 + g_part * KV) < p.Co, h_chok = (ci0 + g_part * KV) < p.Ci;
+        uint32_t slot_ok = 0;   // bit i: g slot i lies in the tile; bit NVG + i: h slot i lies in the halo tile
+#pragma unroll
+        for (int i = 0; i < NVG; ++i) {
+            const int m = (ltid + i * NL) / VPX;
+            const int ty = fdiv(m, k.r_TW);
+            g_ty[i] = ty, g_tx[i] = m - ty * p.TW;
+            if (m < tilepx && g_chok) slot_ok |= 1u << i;
+        }
+        int h_r[NVH], h_c[NVH];
+        uint32_t h_inside = 0;
+#pragma unroll
+        for (int i = 0; i < NVH; ++i) {
+            const int hp = (ltid + i * NL) / VPX, hr = fdiv(hp, k.r_HC);
+            h_r[i] = hr, h_c[i] = hp - hr * k.HC;
+            if (hp < k.HP && h_chok) slot_ok |= 1u << (NVG + i);
+            if (hp < k.HP) h_inside |= 1u << (NVG + i);   // LDS rows to write (zeros when the channel chunk is beyond Ci)
+        }
+        V16 rgv[2][NVG], rgq[2][GQ ? NVG : 1], rhv[2][NVH];
+        uint32_t okm[2] = {0u, 0u};
+        // Byte offset of a slot = (tile term, scalar unit) + (slot term, computed once) - wraps * (row-pitch term): the only
+        // per-slot multiplies left are 24-bit ones (v_mul_lo_u32 / v_mad_u64_u32 are quarter rate, and with one loader wave
+        // per SIMD the address arithmetic was a third of a tile's time).  32-bit offsets beside a scalar base: the host
+        // routes tensors beyond 4 GB, or with row terms beyond 2^23, to the uniform kernel.
+        const int g_cbytes = p.Co * (int)sizeof(T), h_cbytes = p.Ci * (int)sizeof(T);
+        const int g_wrap = -p.Wo * g_cbytes;                       // one image boundary crossed: real row index one less
+        const int h_wrap = (p.Hi - k.PI) * p.Wi * h_cbytes;
+        const int n_vp = -vpitch, n_PI = -k.PI;
+        uint32_t g_lo[NVG], h_lo[NVH];
+#pragma unroll
+        for (int i = 0; i < NVG; ++i) g_lo[i] = (uint32_t)((g_ty[i] * p.Wo + g_tx[i]) * g_cbytes + (co0 + g_part * KV) * (int)sizeof(T));
+#pragma unroll
+        for (int i = 0; i < NVH; ++i) h_lo[i] = (uint32_t)((h_r[i] * p.Wi + h_c[i]) * h_cbytes + (ci0 + g_part * KV) * (int)sizeof(T));
+        auto fetch = [&](auto SET, int t) __attribute__((always_inline)) {
+            constexpr int S = decltype(SET)::value;
+            // tile terms on the scalar unit
+            const int tr = sdiv(t, k.m_tc), tc = t - tr * k.tiles_c;
+            const int vr0 = tr * p.TH, c0 = tc * p.TW;
+            const int gb0 = sdiv(vr0, k.m_vp), gy0 = vr0 - gb0 * vpitch;
+            const uint32_t g_t = (uint32_t)(((vr0 - gb0) * p.Wo + c0) * g_cbytes);
+            uint32_t ok = 0;
+#pragma unroll
+            for (int i = 0; i < NVG; ++i) {
+                const int oy0 = gy0 + g_ty[i], c = c0 + g_tx[i];
+                const int wr_ = fdiv(oy0, k.r_vp);
+                const int oy = mad24_vsv(wr_, n_vp, oy0);
+                const bool in = ((slot_ok >> i) & 1u) & (gb0 + wr_ < p.B) & (oy < p.Ho) & (c < p.Wo);
+                const uint32_t off = in ? (uint32_t)mad24_vsv(wr_, g_wrap, (int)(g_t + g_lo[i])) : 0u;
+                ok |= in ? 1u << i : 0u;
+                rgv[S][i] = ldg16((const char*)io.g.x + off);
+                if (GQ) rgq[S][i] = ldg16((const char*)io.g.y + off);
+            }
+            const int vrs = vr0 * p.stride, cb = c0 * p.stride - k.pad;
+            const int hb0 = sdiv(vrs, k.m_PI), hy0 = vrs - hb0 * k.PI - k.pad;
+            const uint32_t h_t = (uint32_t)(((hb0 * p.Hi + hy0) * p.Wi + cb) * h_cbytes);
+#pragma unroll
+            for (int i = 0; i < NVH; ++i) {
+                const int iy0 = hy0 + h_r[i], ix = cb + h_c[i];
+                const int wr_ = fdiv(iy0 < 0 ? 0 : iy0, k.r_PI);
+                const int iy = mad24_vsv(wr_, n_PI, iy0);
+                const bool in = ((slot_ok >> (NVG + i)) & 1u) & (iy0 >= 0) & (ix >= 0) & (ix < p.Wi) & (hb0 + wr_ < p.B) & (iy < p.Hi);
+                const uint32_t off = in ? (uint32_t)mad24_vsv(wr_, h_wrap, (int)(h_t + h_lo[i])) : 0u;
+                ok |= in ? 1u << (NVG + i) : 0u;
+                rhv[S][i] = ldg16((const char*)io.h.x + off);
+            }
+            okm[S] = ok;
+        };
+        const float relu_lo = io.h.relu ? 0.f : -INFINITY;
+        // this thread's channel constants live in registers for the whole launch (its channel chunk never changes)
+        float cgr[3][KV], chr_[2][KV];
+        auto write_lds = [&](auto SET, int buf) __attribute__((always_inline)) {
+            constexpr int S = decltype(SET)::value;
+            char* sG = smem + k.off_g + buf * bufsz;
+            char* sH = smem + k.off_h + buf * bufsz;
+#pragma unroll
+            for (int i = 0; i < NVG; ++i) {
+                V16 val = rgv[S][i];
+                if (GQ) val = xform_bnbwd<T>(val, rgq[S][i], cgr[0], cgr[1], cgr[2]);
+                mask16(val, (okm[S] >> i) & 1u);
+                const int v = ltid + i * NL;
+                *reinterpret_cast<V16*>(sG + (v / VPX) * PS + g_part * 16) = val;
+            }
+#pragma unroll
+            for (int i = 0; i < NVH; ++i) {
+                V16 val = rhv[S][i];
+                if (io.h.mode == STL_SRC_BN) val = xform_bn<T>(val, chr_[0], chr_[1], relu_lo);
+                mask16(val, (okm[S] >> (NVG + i)) & 1u);
+                const int v = ltid + i * NL;
+                if ((h_inside >> (NVG + i)) & 1u) *reinterpret_cast<V16*>(sH + (v / VPX) * PS + g_part * 16) = val;
+            }
+        };
+        constexpr std::integral_constant<int, 0> I0{};
+        constexpr std::integral_constant<int, 1> I1{};
+        int t = bsplit;
+        if (ntile > 0) fetch(I0, t);
+        if (ntile > 1) fetch(I1, t + step);
+        if (cw) {
+            float a = 0.f, b = 0.f, cc = 0.f;
+            if (cok) {
+                if (cg) src_raw_finish(io.g, raw, a, b, cc);
+                else src_raw_finish(io.h, raw, a, b, cc);
+            }
+            if (cg) cgc[cch] = a, cgc[32 + cch] = b, cgc[64 + cch] = cc;
+            else chc[cch] = a, chc[32 + cch] = b;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the constants are in LDS
+        asm volatile("s_barrier" ::: "memory");   // (A) constants visible to the four loader waves (the compute waves take part in the barrier)
+#pragma unroll
+        for (int e = 0; e < KV; ++e) {
+            cgr[0][e] = cgc[g_part * KV + e], cgr[1][e] = cgc[32 + g_part * KV + e], cgr[2][e] = cgc[64 + g_part * KV + e];
+            chr_[0][e] = chc[g_part * KV + e], chr_[1][e] = chc[32 + g_part * KV + e];
+        }
+        // tile i -> buffer i & 1; one barrier after every write (the compute waves wait at the same barrier before reading)
+        int i = 0;
+        while (i < ntile) {
+#ifndef STL_WS_PROBE
+#define STL_WS_PROBE 0   // timing probes (wrong numerics): 1 = no MFMA loop, 2 = no global loads after the prologue, 3 = no LDS writes
+#endif
+            if (STL_WS_PROBE != 3) write_lds(I0, i & 1);
+            if (STL_WS_PROBE != 2 && i + 2 < ntile) fetch(I0, t + 2 * step);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            asm volatile("s_barrier" ::: "memory");
+            ++i, t += step;
+            if (i >= ntile) break;
+            if (STL_WS_PROBE != 3) write_lds(I1, i & 1);
+            if (STL_WS_PROBE != 2 && i + 2 < ntile) fetch(I1, t + 2 * step);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            asm volatile("s_barrier" ::: "memory");
+            ++i, t += step;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- compute waves
+    const int mt = wave >> 1, nt = wave & 1;
+    const uint32_t lterm = sizeof(T) == 2 ? (lane & 3) * 8 : (lane & 15) * 4;
+    uint32_t gaw[NR], hbw[NKT][NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int c = sizeof(T) == 2 ? 8 * g + 4 * i + ((lane & 15) >> 2) : 4 * g + i;
+        gaw[i] = (uint32_t)(uintptr_t)(smem + k.off_g) + c * PS + lterm + mt * 16 * (int)sizeof(T);
+#pragma unroll
+        for (int s_ = 0; s_ < NKT; ++s_) {
+            int m = s_ * KSTEP + c;
+            if (m >= tilepx) m = 0;
+            const int ty = fdiv(m, k.r_TW), tx = m - ty * p.TW;
+            hbw[s_][i] = (uint32_t)(uintptr_t)(smem + k.off_h) + ((ty * p.stride) * k.HC + tx * p.stride) * PS + lterm + nt * 16 * (int)sizeof(T);
+        }
+    }
+    f32x4 acc[TAPS];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) acc[tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_barrier" ::: "memory");   // (A)
+    for (int i = 0; i < ntile; ++i) {
+        asm volatile("s_barrier" ::: "memory");   // tile i is in buffer i & 1
+        const uint32_t boff = (uint32_t)((i & 1) * bufsz);
+        constexpr int NJ = NKT * TAPS, PF = TAPS >= 4 ? 6 : 2;
+        uint32_t ga[NR], hb[NKT][NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            ga[r] = gaw[r] + boff;
+            asm volatile("" : "+v"(ga[r]));
+#pragma unroll
+            for (int s_ = 0; s_ < NKT; ++s_) {
+                hb[s_][r] = hbw[s_][r] + boff;
+                asm volatile("" : "+v"(hb[s_][r]));
+            }
+        }
+        V16 aq[2], bq[PF];
+        auto bfrag = [&](int j) __attribute__((always_inline)) {
+            const int s_ = j / TAPS, tap = j % TAPS;
+            uint32_t ad[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) ad[r] = hb[s_][r] + (tap / KS) * hrow;
+            return frag_at<T>(ad, (tap % KS) * PS);
+        };
+        aq[0] = frag_at<T>(ga, 0);
+#pragma unroll
+        for (int j = 0; j < PF - 1 && j < NJ; ++j) bq[j] = bfrag(j);
+#pragma unroll
+        for (int j = 0; j < (STL_WS_PROBE == 1 ? 1 : NJ); ++j) {
+            const int s_ = j / TAPS, jt = j % TAPS;
+            if (jt == 0 && s_ + 1 < NKT) aq[(s_ + 1) & 1] = frag_at<T>(ga, (s_ + 1) * KSTEP * PS);
+            if (j + PF - 1 < NJ) bq[(j + PF - 1) % PF] = bfrag(j + PF - 1);
+            mma16<T>(acc[jt], aq[s_ & 1], bq[j % PF]);
+        }
+    }
+    {   // every compute wave writes its quadrant, all taps, of the block's slab [Co][taps][Ci]
+        float* slab = io.partial + (size_t)bsplit * p.Co * TAPS * p.Ci;
+        const int ci = ci0 + nt * 16 + (lane & 15), co = co0 + mt * 16 + 4 * g;
+        float* dst = slab + (size_t)co * TAPS * p.Ci + ci;
+        if (ci < p.Ci) {
+#pragma unroll
+            for (int jt = 0; jt < TAPS; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co + r < p.Co) dst[((size_t)r * TAPS + jt) * p.Ci] = acc[jt][r];
+        }
+    }
+}
+
+template <typename T, int KS, int NVH, bool GQ>
+int launch_ws(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ws_kernel<T, KS, NVH, GQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((wgrad_ws_kernel<T, KS, NVH, GQ>), grid, dim3(512), lds, st, k);
+    STL_LAUNCH_CHECK("conv_wgrad_ws");
+    return 0;
+}
+
 template <typename T, int KS, int NVH, bool GQ, int TPX = 128, int NW = 4>
 int launch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
     constexpr int OCC = (NVH * NW <= 24 && TPX == 128 && sizeof(T) == 2) ? 2 : 1;
@@ -659,6 +940,21 @@ int dispatch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
         }
         return stl_set_error("wgrad: 256-pixel tiles need bf16 and a halo of at most 384 pixels (have %d)", k.HP);
     }
+    if constexpr (KS == 3) {   // wave-specialised kernel (STL_WGRAD_WS, default on): loaders beside MFMA waves, double-buffered LDS
+        static const int ws_env = getenv("STL_WGRAD_WS") ? atoi(getenv("STL_WGRAD_WS")) : 1;
+        const int nvl = ceil_div(k.HP * vpx, 256);
+        const size_t lds_ws = (size_t)k.off_g + 2 * ((size_t)(k.off_h - k.off_g) + (size_t)k.HP * k.psh);
+        // its loaders address with 24-bit multiplies and 32-bit byte offsets
+        const int64_t gpx = (int64_t)k.p.B * k.p.Ho * k.p.Wo, hpx = (int64_t)k.p.B * k.p.Hi * k.p.Wi;
+        const bool small = gpx * k.p.Co * (int64_t)sizeof(T) < ((int64_t)1 << 32) && hpx * k.p.Ci * (int64_t)sizeof(T) < ((int64_t)1 << 32) &&
+                           (int64_t)k.p.Wo * k.p.Co * (int64_t)sizeof(T) < (1 << 23) &&
+                           (int64_t)(k.PI > k.p.Hi ? k.PI - k.p.Hi : k.p.Hi - k.PI) * k.p.Wi * k.p.Ci * (int64_t)sizeof(T) < (1 << 23) &&
+                           k.PI < (1 << 12) && k.tiles_c < (1 << 12) && (int64_t)k.npt * k.p.TH * k.p.stride < (1 << 20);
+        if (ws_env && small && lds_ws <= 150 * 1024) {
+            if (nvl <= 3) return gq ? launch_ws<T, KS, 3, true>(k, grid, lds_ws, st) : launch_ws<T, KS, 3, false>(k, grid, lds_ws, st);
+            if (nvl <= 6) return gq ? launch_ws<T, KS, 6, true>(k, grid, lds_ws, st) : launch_ws<T, KS, 6, false>(k, grid, lds_ws, st);
+        }
+    }
     if constexpr (KS == 3) {   // 8 waves: quadrants x two tap groups, half the staging work per thread (bf16 and fp32)
         static const int nw_env = getenv("STL_WGRAD_NW") ? atoi(getenv("STL_WGRAD_NW")) : 8;
         if (nw_env == 8) {
@@ -742,6 +1038,8 @@ static int wgrad_run(const stl_wgrad* const* ps, int ng, void* stream) {
     k.tiles_c = ceil_div(p.Wo, p.TW);
     k.npt = ceil_div(p.B * (p.Ho + 1), p.TH) * k.tiles_c;
     k.r_TW = 1.0f / p.TW, k.r_HC = 1.0f / k.HC, k.r_tc = 1.0f / k.tiles_c, k.r_vp = 1.0f / (p.Ho + 1), k.r_PI = 1.0f / k.PI;
+    const unsigned long long two32 = 1ull << 32;
+    k.m_tc = (two32 + k.tiles_c - 1) / k.tiles_c, k.m_vp = (two32 + p.Ho) / (p.Ho + 1), k.m_PI = (two32 + k.PI - 1) / k.PI;
     STL_CHECK((int64_t)k.npt < (1 << 21) && (int64_t)p.B * k.PI < (1 << 21), "wgrad: too many tiles");
     hipStream_t st = (hipStream_t)stream;
     if (wgrad_chunk(p) == 64) {

@@ -686,9 +686,10 @@ class Engine:
         data-gradient chain.)  Where the network has fewer branches than streams -- stage 3, stage 2, and the
         single-branch tail (layer1, stem), 40 % of backward -- the idle queues take the off-chain work: each such
         launch goes to the least-loaded stream among the idle ones and its own, by accumulated estimated time.
-        In the tail only ONE idle queue is used: its launches stream 113 MB tensors at 3-4 TB/s each, and three
+        In the tail only TWO idle queues are used: its launches stream 113 MB tensors at 3-4 TB/s each, and three
         weight gradients beside the data-gradient chain slow every one of them down by more than the overlap
-        buys (tail queues 3 / 2 / 1 / 0: 16.98 / 16.86 / 16.82 / 17.33 ms per step)."""
+        buys (round 2, tail queues 3 / 2 / 1 / 0: 16.98 / 16.86 / 16.82 / 17.33 ms per step; round 3 with ungrouped
+        tail launches 3 / 2 / 1: 14.87 / 14.72 / 14.82)."""
         acc = [0.0] * self.nstreams
         out = []
         for op in ops:
@@ -700,7 +701,7 @@ class Engine:
                 if os.environ.get("STLPOSE_BALANCE", "idle") == "idle":
                     cands = list(range(active, self.nstreams)) + [own]
                     nq = int(os.environ.get("STLPOSE_OFFCHAIN_QUEUES", "0"))   # 0 = every idle queue
-                    tq = int(os.environ.get("STLPOSE_TAIL_QUEUES", "1"))       # same, for the single-branch tail only (0 = all three)
+                    tq = int(os.environ.get("STLPOSE_TAIL_QUEUES", "2"))       # same, for the single-branch tail only (0 = all three); with ungrouped tail launches 1 / 2 / 3: 14.82 / 14.72 / 14.87
                     if active == 1 and tq:
                         cands = list(range(1, min(1 + tq, self.nstreams))) + [own]
                     elif nq:
@@ -778,6 +779,14 @@ class Engine:
             budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS64", "512"))
         elif kks == 1 and self.esz == 2:
             budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS_K1", str(budget)))
+        # The single-branch tail of backward (layer1, stem, transition1) is one serial data-gradient chain beside three idle
+        # queues: a group there fills only when the chain has walked through ALL its members (every layer1 group completes
+        # at the first block, i.e. at the very end of the step), so grouped weight gradients pile up behind the chain.
+        tail = self._active_of(ci.key) == 1
+        gmax = capi.WGRAD_GROUP_MAX
+        if tail:
+            budget = int(os.environ.get("STLPOSE_TAIL_BLOCKS", str(budget)))
+            gmax = int(os.environ.get("STLPOSE_TAIL_GROUP", "1"))   # 4 / 2 / 1: 15.02 / 14.81 / 14.82 ms per step; with two tail queues 14.73 / 14.72
         top = max(1, min(npt, budget // chunks if chunks <= budget else 1))
         wg.nsplit = min(range(1, top + 1), key=lambda ns: (math.ceil(npt / ns) + 0.004 * ns * chunks / 8, ns))
         wg.h = self._src(x)
@@ -789,7 +798,7 @@ class Engine:
         # block walks gsize times as many pixel tiles, and gsize times fewer split-K slabs are written and reduced.
         gsize = 1
         if (ctile == 32 or os.environ.get("STLPOSE_WGRAD_GROUP64", "1") != "0") and not big and os.environ.get("STLPOSE_SKIP_WGRAD", "0") == "0":
-            gsize = max(1, min(int(os.environ.get("STLPOSE_WGRAD_GROUP", "4")), capi.WGRAD_GROUP_MAX, max(1, budget // chunks),
+            gsize = max(1, min(int(os.environ.get("STLPOSE_WGRAD_GROUP", "4")), gmax, max(1, budget // chunks),
                                self._wg_count.get((x.C, y.C, kks, kstride, x.H, x.W), 1) if os.environ.get("STLPOSE_WGRAD_COUNT", "0") != "0" else 99))
         if gsize > 1:
             bg = budget // gsize
