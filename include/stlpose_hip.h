@@ -299,6 +299,8 @@ int stl_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H,
 #define STL_OP_REDUCE_RANGE 8 /* stl_reduce_slabs over a sub-range of the table (a gradient bucket) */
 #define STL_OP_BN_GRADS_RANGE 9 /* stl_bn_param_grads over a sub-range of the table */
 #define STL_OP_WGRAD_GROUP 10   /* stl_conv_wgrad_group */
+#define STL_OP_OPTIM_SLICE 11   /* stl_adam_slice / stl_sgd_slice of a gradient bucket, behind its reductions */
+#define STL_OP_WPREP_RANGE 12   /* stl_weight_prep_range of the bucket's convolutions (the NEXT step's kernel-layout weights) */
 /* A gradient bucket = a contiguous slice of the flat gradient buffer whose weight-gradient slabs and
  * BatchNorm reductions are complete at some point of the backward program.  Reducing it there (and
  * recording an event) lets the data-parallel all-reduce of that slice start while the rest of
@@ -306,6 +308,11 @@ int stl_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H,
 typedef struct stl_reduce_range { const float* partials; float* grads; const stl_slab* tab; int32_t n, blk_base, nblocks, pad_; } stl_reduce_range;
 typedef struct stl_bn_range { const double* rstats; float* grads; const stl_bnrec* tab; int32_t n, pad_; } stl_bn_range;
 int stl_reduce_slabs_range(const stl_reduce_range* r, void* stream);
+/* Optimiser of one gradient bucket as a program op (single-process training: with data parallelism the collective sits
+ * between a bucket's reduction and its optimiser, and the host issues the slices, see train_step.py).  kind 0 = Adam,
+ * 1 = SGD (v unused).  Reference: optimizer.step() after loss.backward(), 02_train.py:113-114. */
+typedef struct stl_optim_slice { int32_t kind, pad_; float* p; const float* g; float* m; float* v; int64_t n; const float* hyper; const int32_t* step; } stl_optim_slice;
+typedef struct stl_wprep_range { int32_t dtype, n, blk_base, nblocks; const float* master; void* wk; const stl_wprep* tab; } stl_wprep_range;
 typedef struct stl_patch { int32_t dtype, B, H, W, stride, pad_; const float* img; void* out; const float* mean3; const float* std3; } stl_patch;
 typedef struct stl_head { int32_t dtype, B, H, W, Ci, J; const void* x; const float* w; const float* bias; float* out; } stl_head;
 typedef struct stl_head_bwd { int32_t dtype, B, H, W, Ci, J, nblk, pad_; const void* x; const float* w; const float* dout; void* dx; float* partial; } stl_head_bwd;

@@ -101,9 +101,18 @@ class BNRange(C.Structure):
     _fields_ = [("rstats", vp), ("grads", vp), ("tab", vp), ("n", i32), ("pad_", i32)]
 
 
+class OptimSlice(C.Structure):   # stl_optim_slice
+    _fields_ = [("kind", i32), ("pad_", i32), ("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", C.c_int64), ("hyper", vp), ("step", vp)]
+
+
+class WPrepRange(C.Structure):   # stl_wprep_range
+    _fields_ = [("dtype", i32), ("n", i32), ("blk_base", i32), ("nblocks", i32), ("master", vp), ("wk", vp), ("tab", vp)]
+
+
 OP_KIND = {"stl_conv_forward": 0, "stl_conv_wgrad": 1, "stl_fuse_forward": 2, "stl_fuse_backward": 3,
            "stl_upsample_backward": 4, "stl_patch3x3": 5, "stl_head_forward": 6, "stl_head_backward": 7,
-           "stl_reduce_slabs_range": 8, "stl_bn_grads_range": 9, "stl_conv_wgrad_group": 10}
+           "stl_reduce_slabs_range": 8, "stl_bn_grads_range": 9, "stl_conv_wgrad_group": 10,
+           "stl_optim_slice": 11, "stl_wprep_range": 12}   # the last two exist as program ops only
 
 # name -> argtypes (restype is always int unless noted); every symbol include/stlpose_hip.h declares
 SIGNATURES = {

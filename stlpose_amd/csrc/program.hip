@@ -104,6 +104,17 @@ extern "C" int stl_program_run(void* h, void* const* streams) {
                 rc = stl_head_backward(a->dtype, a->x, a->w, a->dout, a->dx, a->partial, a->nblk, a->B, a->H, a->W, a->Ci, a->J, st);
                 break;
             }
+            case STL_OP_OPTIM_SLICE: {
+                const stl_optim_slice* a = static_cast<const stl_optim_slice*>(o.desc);
+                rc = a->kind == 0 ? stl_adam_slice(a->p, a->g, a->m, a->v, a->n, a->hyper, a->step, st)
+                                  : stl_sgd_slice(a->p, a->g, a->m, a->n, a->hyper, a->step, st);
+                break;
+            }
+            case STL_OP_WPREP_RANGE: {
+                const stl_wprep_range* a = static_cast<const stl_wprep_range*>(o.desc);
+                rc = stl_weight_prep_range(a->dtype, a->master, a->wk, a->tab, a->n, a->blk_base, a->nblocks, st);
+                break;
+            }
             case STL_OP_REDUCE_RANGE: rc = stl_reduce_slabs_range(static_cast<const stl_reduce_range*>(o.desc), st); break;
             case STL_OP_BN_GRADS_RANGE: {
                 const stl_bn_range* a = static_cast<const stl_bn_range*>(o.desc);

@@ -48,7 +48,28 @@ struct WgK {
     int off_cg, off_ch, off_g, off_h;
     float r_TW, r_HC, r_tc, r_vp, r_PI;  // reciprocals for fdiv
     unsigned long long m_tc, m_vp, m_PI;  // ceil(2^32 / d): exact n / d = (n * m) >> 32 on the scalar unit for n * d < 2^32
+    int xmap, units, gy, gz;   // XCD-aware block order (see wg_block): units = ng * nsplit pixel ranges, gy x gz channel chunks
 };
+
+// Which (member, split, co chunk, ci chunk) a block works on.  Plain order: grid (ng * nsplit, gy, gz).  XCD-aware order
+// (k.xmap, 1-D grid): workgroups go to the eight XCDs round-robin by linear id, so the gy * gz chunk blocks of ONE pixel
+// range get ids 8 apart -- same XCD, dispatched back to back -- and share its L2: every chunk block of a range reads the
+// same pixels (its 32- or 64-channel slice of g, and of h), and two adjacent 32-channel slices share each 128-byte line.
+struct WgBlock { int member, bsplit, cy, cz; bool live; };
+__device__ __forceinline__ WgBlock wg_block(const WgK& k) {
+    WgBlock b;
+    if (!k.xmap) {
+        b.member = __builtin_amdgcn_readfirstlane(blockIdx.x / k.p.nsplit);
+        b.bsplit = blockIdx.x - b.member * k.p.nsplit, b.cy = blockIdx.y, b.cz = blockIdx.z, b.live = true;
+        return b;
+    }
+    const int nc = k.gy * k.gz, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int ju = __builtin_amdgcn_readfirstlane(j / nc), chunk = j - ju * nc, unit = ju * 8 + xcd;
+    b.live = unit < k.units;
+    b.member = __builtin_amdgcn_readfirstlane(unit / k.p.nsplit), b.bsplit = unit - b.member * k.p.nsplit;
+    b.cy = __builtin_amdgcn_readfirstlane(chunk / k.gz), b.cz = chunk - b.cy * k.gz;
+    return b;
+}
 
 
 template <typename T>
@@ -130,11 +151,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
     const stl_wgrad& p = k.p;
     // grouped launch: blockIdx.x = member * nsplit + split.  The member's tensors come from k.io[member] (a uniform,
     // run-time index into the kernel arguments: scalar loads), everything geometric from k.p.
-    const int member = blockIdx.x / p.nsplit, bsplit = blockIdx.x - member * p.nsplit;
+    const WgBlock wb = wg_block(k);
+    if (!wb.live) return;
+    const int member = wb.member, bsplit = wb.bsplit;
     const stl_wgrad_io& io = k.io[member];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
     const int mt = (wave & 3) >> 1, nt = wave & 1, tg = wave >> 2;
-    const int co0 = blockIdx.y * 32, ci0 = blockIdx.z * 32;
+    const int co0 = wb.cy * 32, ci0 = wb.cz * 32;
     WSTAMP(0);
     float* cgc = reinterpret_cast<float*>(smem + k.off_cg);  // [3][32]
     float* chc = reinterpret_cast<float*>(smem + k.off_ch);  // [2][32]
@@ -399,13 +422,14 @@ __global__ __launch_bounds__(512, WS_WPE) void wgrad_ws_kernel(const WgK k) {
     constexpr int PS = 32 * (int)sizeof(T) + 16;
     constexpr int NKT = TPX / KSTEP;
     const stl_wgrad& p = k.p;
-    const int member = __builtin_amdgcn_readfirstlane(blockIdx.x / p.nsplit);   // the division runs on the vector unit: back to scalars,
-    const int bsplit = blockIdx.x - member * p.nsplit;                           // or every tile term below stays vector arithmetic
+    const WgBlock wb = wg_block(k);   // (its divisions run on the vector unit and come back as scalars: otherwise every tile term
+    if (!wb.live) return;             // below stays vector arithmetic)
+    const int member = wb.member, bsplit = wb.bsplit;
     const stl_wgrad_io& io = k.io[member];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wave >= 4;
-    const int co0 = blockIdx.y * 32, ci0 = blockIdx.z * 32;
+    const int co0 = wb.cy * 32, ci0 = wb.cz * 32;
     float* cgc = reinterpret_cast<float*>(smem + k.off_cg);  // [3][32]
     float* chc = reinterpret_cast<float*>(smem + k.off_ch);  // [2][32]
     const int bufsz = k.off_h - k.off_g + k.HP * PS;          // one LDS image: g tile + h halo tile
@@ -675,11 +699,13 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(const WgK k) {
     constexpr int NVG = TPX * VPX / 256;    // g staging vectors per thread
     constexpr int NKS = TPX / KSTEP;        // K steps per tile, all done by every wave
     const stl_wgrad& p = k.p;
-    const int member = blockIdx.x / p.nsplit, bsplit = blockIdx.x - member * p.nsplit;   // grouped launch, see wgrad_kernel
+    const WgBlock wb = wg_block(k);   // grouped launch, see wgrad_kernel
+    if (!wb.live) return;
+    const int member = wb.member, bsplit = wb.bsplit;
     const stl_wgrad_io& io = k.io[member];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
-    const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+    const int co0 = wb.cy * 64, ci0 = wb.cz * 64;
     float* cgc = reinterpret_cast<float*>(smem + k.off_cg);  // [3][64]
     float* chc = reinterpret_cast<float*>(smem + k.off_ch);  // [2][64]
     char* sG = smem + k.off_g;
@@ -914,6 +940,16 @@ int dispatch64(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
     return stl_set_error("wgrad64: halo of %d pixels is too large for a %d-pixel tile", k.HP, k.p.TH * k.p.TW);
 }
 
+// launch grid + block-order fields of k (wg_block): XCD-aware order when there is more than one channel chunk
+// (STL_WGRAD_XCD=0: plain 3-D grid)
+dim3 wg_grid(WgK& k, int units, int gy, int gz) {
+    static const int xcd_env = getenv("STL_WGRAD_XCD") ? atoi(getenv("STL_WGRAD_XCD")) : 1;
+    k.units = units, k.gy = gy, k.gz = gz;
+    k.xmap = xcd_env && gy * gz > 1;
+    if (!k.xmap) return dim3(units, gy, gz);
+    return dim3(8 * ceil_div(units, 8) * gy * gz, 1, 1);
+}
+
 // channel tile (64 or 32) of the kernel variant stl_conv_wgrad picks for this problem
 int wgrad_chunk(const stl_wgrad& p) {
     // Default: 1x1 convolutions only ("k1").  There the wide variant halves the re-reads of the 113 MB
@@ -953,6 +989,7 @@ int dispatch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
         if (ws_env && small && lds_ws <= 150 * 1024) {
             if (nvl <= 3) return gq ? launch_ws<T, KS, 3, true>(k, grid, lds_ws, st) : launch_ws<T, KS, 3, false>(k, grid, lds_ws, st);
             if (nvl <= 6) return gq ? launch_ws<T, KS, 6, true>(k, grid, lds_ws, st) : launch_ws<T, KS, 6, false>(k, grid, lds_ws, st);
+            if (nvl <= 9) return gq ? launch_ws<T, KS, 9, true>(k, grid, lds_ws, st) : launch_ws<T, KS, 9, false>(k, grid, lds_ws, st);   // stride 2: 33 x 17 halo
         }
     }
     if constexpr (KS == 3) {   // 8 waves: quadrants x two tap groups, half the staging work per thread (bf16 and fp32)
@@ -1049,7 +1086,7 @@ static int wgrad_run(const stl_wgrad* const* ps, int ng, void* stream) {
         const size_t lds64 = (size_t)k.off_h + (size_t)k.HP * k.psh;
         STL_CHECK(lds64 <= 160 * 1024, "wgrad64: tile needs %zu B of LDS (>160 KiB)", lds64);
         STL_CHECK(p.nsplit <= k.npt || p.nsplit == 1, "wgrad: nsplit %d > tiles %d", p.nsplit, k.npt);
-        dim3 grid64(p.nsplit * ng, ceil_div(p.Co, 64), ceil_div(p.Ci, 64));
+        dim3 grid64 = wg_grid(k, p.nsplit * ng, ceil_div(p.Co, 64), ceil_div(p.Ci, 64));
         return p.ks == 3 ? dispatch64<3>(k, grid64, lds64, st) : dispatch64<1>(k, grid64, lds64, st);
     }
     const int esz = p.dtype == STL_BF16 ? 2 : 4;
@@ -1063,7 +1100,7 @@ static int wgrad_run(const stl_wgrad* const* ps, int ng, void* stream) {
     size_t lds = (size_t)k.off_h + szH;
     STL_CHECK(lds <= 160 * 1024, "wgrad: tile needs %zu B of LDS (>160 KiB)", lds);
     STL_CHECK(p.nsplit <= k.npt || p.nsplit == 1, "wgrad: nsplit %d > tiles %d", p.nsplit, k.npt);
-    dim3 grid(p.nsplit * ng, ceil_div(p.Co, 32), ceil_div(p.Ci, 32));
+    dim3 grid = wg_grid(k, p.nsplit * ng, ceil_div(p.Co, 32), ceil_div(p.Ci, 32));
     if (p.dtype == STL_BF16) return p.ks == 3 ? dispatch<__bf16, 3>(k, grid, lds, st) : dispatch<__bf16, 1>(k, grid, lds, st);
     return p.ks == 3 ? dispatch<float, 3>(k, grid, lds, st) : dispatch<float, 1>(k, grid, lds, st);
 }

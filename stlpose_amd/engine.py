@@ -409,7 +409,7 @@ class Engine:
         # program, so the step has no serial tail, and an event a data-parallel all-reduce can wait on.
         self.buckets: List[dict] = []
         bucket_min = int(float(os.environ.get("STLPOSE_BUCKET_MB", "32")) * (1 << 20) / 4)   # 16 -> 32 MB: 16.79 -> 16.66 ms/step (fewer, larger reductions and collectives)
-        bk = dict(done=0, lo=st.nparam, hi=st.nparam, slab0=0, reads=[], strm=0)
+        bk = dict(done=0, lo=st.nparam, hi=st.nparam, slab0=0, reads=[], strm=0, wuse=[])
         # The serial tail of backward (layer1 + stem: one branch, 113 MB tensors) finishes last.  Close a bucket
         # where it begins, whatever its size, so that the final slab reduction (the only work left after the last
         # weight gradient, in front of the optimiser) covers just the stem / layer1 slabs instead of every layer
@@ -448,13 +448,13 @@ class Engine:
             for key in list(self._wg_pending):                     # the bucket's slab reduction reads every member's slabs
                 self._flush_wgrad_group(ops, key, now=True)
             rr, br = capi.ReduceRange(), capi.BNRange()
-            b = dict(lo=bk["lo"], hi=bk["hi"], slab0=bk["slab0"], slab1=len(self.slabs), rr=rr, br=br)
+            b = dict(lo=bk["lo"], hi=bk["hi"], slab0=bk["slab0"], slab1=len(self.slabs), rr=rr, br=br, wuse=list(bk["wuse"]))
             wstrm = bk["strm"]
             ops.append(("stl_reduce_slabs_range", rr, wstrm, list(bk["reads"]), [("bucket", len(self.buckets))]))
             ops.append(("stl_bn_grads_range", br, wstrm, [("bucket", len(self.buckets))], [("bucketbn", len(self.buckets))]))
             b["op"] = len(ops) - 1
             self.buckets.append(b)
-            bk.update(done=0, hi=bk["lo"], slab0=len(self.slabs), reads=[])
+            bk.update(done=0, hi=bk["lo"], slab0=len(self.slabs), reads=[], wuse=[])
         self._nactive: Dict[int, int] = {}   # id(desc) -> branch streams busy with the data-gradient chain around that op
         cur_active = self.nstreams
 
@@ -610,7 +610,10 @@ class Engine:
                     d.mask_bn = self._src(x)
                     d.red = self.rstats.data_ptr() + 8 * x.bn.stats_off
                 d.out = out.data_ptr()
-                ops.append(("stl_conv_forward", d, strm, dreads, [out.data_ptr()] + dwrites))
+                # ("wuse", layer): this launch is the last reader of the layer's kernel-layout weights and BatchNorm
+                # parameters in the step -- what an in-program optimiser / weight re-layout of the bucket waits for
+                ops.append(("stl_conv_forward", d, strm, dreads, [out.data_ptr(), ("wuse", ci.master_off)] + dwrites))
+                bk["wuse"].append(("wuse", ci.master_off))
         bucket_close(force=True)
         for o in ops[n_before:]:
             self._nactive.setdefault(id(o[1]), cur_active)
@@ -1040,12 +1043,55 @@ class Engine:
             capi.call("stl_bn_running_update", self.stats.data_ptr(), st.bufs.data_ptr(), st.nbt.data_ptr(),
                       self._bn_tab.data_ptr(), len(self.bns), MOMENTUM, stream)
 
-    def backward(self, stream: int):
-        """expects self.dout filled; leaves dL/dparam in store.grads (overwrites)."""
+    def backward(self, stream: int, fused_optim: bool = False):
+        """expects self.dout filled; leaves dL/dparam in store.grads (overwrites).  fused_optim: the program of
+        attach_optimizer (optimiser + next step's weight layouts inside backward)."""
         assert self.training
         st = self.store
         self.rstats.zero_()
-        self._run(self.bwd_ops, stream)   # includes the per-bucket slab reductions and BatchNorm gradients
+        self._run(self.bwd_ops_opt if fused_optim else self.bwd_ops, stream)   # includes the per-bucket slab reductions and BatchNorm gradients
+
+    def attach_optimizer(self, kind: int, p: int, g: int, m: int, v: int, hyper: int, step: int):
+        """Single-process training: the optimiser slice and the next step's kernel-layout weights of every gradient bucket
+        become ops of the backward program (``backward(stream, fused_optim=True)``), issued one bucket late on the stream
+        of that later bucket's reductions -- by then the data gradients that still read the bucket's weights / BatchNorm
+        parameters (the ("wuse", layer) tokens both ops wait for) have long finished.  The step then has no serial
+        optimiser (0.13 ms) and weight re-layout (0.10 ms at the start of the next forward) section; no fifth stream is
+        involved (a fifth active hardware queue is time-sliced).  kind: 0 Adam, 1 SGD."""
+        ops = list(self.bwd_ops)
+        at = sorted((b["op"], i) for i, b in enumerate(self.buckets))
+        self._optim_descs = []
+        new_ops, prev = [], None
+
+        def emit(i, strm):
+            b = self.buckets[i]
+            o = capi.OptimSlice()
+            lo, n = b["lo"], b["hi"] - b["lo"]
+            o.kind, o.p, o.g, o.m, o.v, o.n, o.hyper, o.step = kind, p + 4 * lo, g + 4 * lo, m + 4 * lo, (v + 4 * lo) if v else 0, n, hyper, step
+            new_ops.append(("stl_optim_slice", o, strm, [("bucketbn", i)] + b["wuse"], [("optim", i)]))
+            self._optim_descs.append(o)
+            if "conv0" not in b:
+                import bisect
+                offs = [c.master_off for c in self.convs]
+                b["conv0"], b["conv1"] = bisect.bisect_left(offs, b["lo"]), bisect.bisect_left(offs, b["hi"])
+            i0, i1 = b["conv0"], b["conv1"]
+            if i1 > i0:
+                w = capi.WPrepRange()
+                w.dtype, w.n, w.blk_base, w.nblocks = self.dtype, i1 - i0, self._wprep_blk0[i0], self._wprep_blk0[i1] - self._wprep_blk0[i0]
+                w.master, w.wk, w.tab = self.store.master.data_ptr(), self.wk.data_ptr(), self._wprep_tab.data_ptr() + i0 * C.sizeof(capi.WPrep)
+                new_ops.append(("stl_wprep_range", w, strm, [("optim", i)], [("wprep", i)]))
+                self._optim_descs.append(w)
+
+        nxt = dict(at)
+        for idx, op in enumerate(ops):
+            new_ops.append(op)
+            if idx in nxt:
+                if prev is not None:
+                    emit(prev, op[2])
+                prev = nxt[idx]
+        if prev is not None:
+            emit(prev, ops[self.buckets[prev]["op"]][2])
+        self.bwd_ops_opt = new_ops
 
     def bucket_wait(self, i: int, stream: int):
         """Make `stream` wait until gradient bucket i (self.buckets[i]: flat slice [lo, hi)) of the

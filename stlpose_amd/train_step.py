@@ -74,6 +74,14 @@ class TrainStep:
         # replay, so the overlapped per-bucket all-reduce has nothing to wait on -- run eagerly instead
         if self.use_graph and process_group is not None:
             self.use_graph = False
+        # Single process, native replay: optimiser slices and the next step's weight layouts run as ops of the backward
+        # program (engine.attach_optimizer).  With a process group the collective sits between a bucket's reduction and
+        # its optimiser, so the host issues those (_allreduce / _optim).
+        self._fused_optim = (not self.use_graph and self.dp is None and os.environ.get("STLPOSE_FUSED_OPTIM", "0") != "0")   # measured neutral on one MI355X (14.93 vs 14.95 ms per step: the tail of backward it overlaps with is bandwidth-bound too): opt-in
+        if self._fused_optim:
+            self.eng.attach_optimizer(0 if optimizer == ADAM else 1, self.store.master.data_ptr(), self.store.grads.data_ptr(),
+                                      self.m.data_ptr(), self.v.data_ptr() if self.v is not None else 0,
+                                      self.hyper.data_ptr(), self.step_count.data_ptr())
 
     # ------------------------------------------------------------------ pieces
     def set_lr(self, lr: float):
@@ -100,7 +108,7 @@ class TrainStep:
         """Call after changing the model's parameters outside of step() (load_state_dict, manual edits)."""
         self._prepped = False
 
-    def _fwd_bwd(self, update_running: bool = True):
+    def _fwd_bwd(self, update_running: bool = True, fused_optim: bool = False):
         st = torch.cuda.current_stream().cuda_stream
         e = self.eng
         # kernel-layout weights were refreshed bucket by bucket at the end of the previous step
@@ -113,7 +121,11 @@ class TrainStep:
                   self._loss_scale, st)
         if self._loss_scale != 1.0 or self._loss_offset != 0.0:   # the kernel scales only dL/dout
             self.loss.mul_(self._loss_scale).add_(self._loss_offset)
-        e.backward(st)
+        if fused_optim:
+            capi.call("stl_optim_begin_step", self.step_count.data_ptr(), st)
+        e.backward(st, fused_optim=fused_optim)
+        if fused_optim:
+            self._prepped = True   # every bucket's kernel-layout weights were refreshed inside the program
 
     def _optim(self):
         st = torch.cuda.current_stream().cuda_stream
@@ -199,6 +211,8 @@ class TrainStep:
             # land in the already saturated tail of backward; kept for multi-GPU experiments
             self._fwd_bwd()
             self._bucketed_tail()
+        elif self._fused_optim and not self.use_graph:
+            self._fwd_bwd(fused_optim=True)
         else:
             self._fwd_bwd()
             self._allreduce()

@@ -267,3 +267,41 @@ def test_w48_384x288_fp32_train_step_vs_oracle():
     eng = m.engine(4, 384, 288, True)
     merged = {o_[1].Ci for o_ in eng.fwd_ops if o_[0] == "stl_conv_forward" and o_[1].src.mode == capi.SRC_BNADD}
     assert 192 in merged, merged
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opt", ["adam", "sgd"])
+def test_in_program_optimizer_equals_host_issued(opt, monkeypatch):
+    """STLPOSE_FUSED_OPTIM=1 (optimiser slices + next step's weight layouts as ops of the backward program, behind the
+    ("wuse", layer) tokens of the data gradients that still read a bucket's weights) must leave the same weights, moments and
+    running statistics as the host-issued optimiser after three steps on three batches -- a slice applied while a data
+    gradient still reads the old weights, or a stale layout in the next forward, shows up as a different loss / weight.
+    Small buckets so that several optimiser slices sit in the middle of the backward program.  Reference: optimizer.step()
+    after loss.backward(), 02_train.py:113-114."""
+    monkeypatch.setenv("STLPOSE_BUCKET_MB", "8")
+    kw = dict(optimizer="adam", lr=1e-3) if opt == "adam" else dict(optimizer="sgd", lr=1e-2, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    out = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("STLPOSE_FUSED_OPTIM", fused)
+        m = _load_synth(PoseHighResolutionNet("w32", "bf16")).cuda()
+        ts = TrainStep(m, 2, 128, 96, **kw)
+        assert ts._fused_optim == (fused == "1")
+        if fused == "1":
+            names = [o[0] for o in ts.eng.bwd_ops_opt]
+            assert names.count("stl_optim_slice") == len(ts.eng.buckets) >= 4 and names.count("stl_wprep_range") >= 4
+        losses = []
+        for step in range(3):
+            img, tgt, tw = synth_batch(2, 128, 96, seed=500 + step)
+            ts.load_batch(torch.from_numpy(img).cuda(), torch.from_numpy(tgt).cuda(), torch.from_numpy(tw).cuda())
+            losses.append(float(ts.step().item()))
+        torch.cuda.synchronize()
+        out[fused] = (losses, ts.store.master.clone(), ts.m.clone(), ts.store.bufs.clone(), int(ts.step_count.item()))
+    (l0, w0, m0, b0, s0), (l1, w1, m1, b1, s1) = out["0"], out["1"]
+    assert s0 == s1 == 3
+    # split-K slabs are reduced in a fixed order and the optimiser arithmetic is element-wise: only the fp64 atomics of the
+    # BatchNorm statistics can differ in their last bits between two runs
+    np.testing.assert_allclose(l1, l0, rtol=1e-5)
+    for a, b, what in ((w1, w0, "weights"), (m1, m0, "first moment"), (b1, b0, "running statistics")):
+        d = float((a - b).abs().max())
+        ref = float(b.abs().max())
+        assert d <= 2e-4 * ref, f"{what}: max |diff| {d:.3e} of {ref:.3e}"
