@@ -690,11 +690,11 @@ struct Shape {
     int lthr, nva_max; // threads that stage the halo, max staging vectors per such thread
 };
 // 0..4: uniform-wave kernel (conv_core_kernel); 5..7: wave-specialised kernel (conv_ws_kernel)
-constexpr int NSHAPES = 9;   // 8 = 256 px x 32 co (8 waves: two 128-pixel halves share one filter copy and one halo tile)
+constexpr int NSHAPES = 10;  // 8 = 256 px x 32 co (8 waves: two 128-pixel halves share one filter copy and one halo tile); 9 = wave-specialised 128 px x 32 co
 constexpr Shape SHAPES[NSHAPES] = {{128, 64, 256, 0, 256, 9}, {512, 32, 512, 0, 512, 6}, {256, 64, 512, 0, 512, 3},
                                    {256, 128, 512, 0, 512, 3}, {128, 32, 256, 0, 256, 6},
                                    {512, 32, 512, 1, 256, 10}, {256, 64, 512, 1, 256, 6}, {128, 64, 512, 1, 256, 9},
-                                   {256, 32, 512, 0, 512, 3}};
+                                   {256, 32, 512, 0, 512, 3}, {128, 32, 512, 1, 256, 3}};
 
 template <typename T, int KS, bool Q, bool PE>
 int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
@@ -730,6 +730,9 @@ int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStrea
         case 7:
             if (nva <= 3) return launch_ws<T, KS, 2, 4, 3, Q>(k, grid, lds, st);
             if (nva <= 9) return launch_ws<T, KS, 2, 4, 9, Q>(k, grid, lds, st);
+            break;
+        case 9:   // 128 px x 32 co: twice the blocks of shape 7 for the small, deep maps (12x9 at C = 256: 128 -> 256 blocks)
+            if (nva <= 3) return launch_ws<T, KS, 2, 2, 3, Q>(k, grid, lds, st);
             break;
     }
     return stl_set_error("conv: no kernel variant for block shape %d with %d staging vectors per thread", shape, nva);
@@ -842,7 +845,16 @@ Plan choose_plan(const stl_conv& p, int ck) {
         const int want_ws = p.wg_partial ? 0 : getenv("STL_CONV_WS") ? atoi(getenv("STL_CONV_WS"))
                                                   : ((p.stride == 2 || (p.ks == 3 && p.Co >= ws_minco && (int64_t)p.B * p.Ho * p.Wo <= 16384)) ? 1 : 0);
         if (sh.ws != want_ws) continue;
-        if (want_ws && !getenv("STL_CONV_WS") && shape != 7) continue;
+        static const int ws_co32 = getenv("STL_CONV_WS_CO32") ? atoi(getenv("STL_CONV_WS_CO32")) : 256;   // deep small maps on 128 px x 32 co blocks
+        const bool deep_small = ws_co32 && p.stride == 1 && p.ks == 3 && p.Co >= ws_co32 && (int64_t)p.B * p.Ho * p.Wo <= 16384;
+        // (in the step the chains of the low-resolution branches are the critical path of stage 4 -- tools/alone_time.py,
+        // DESIGN.md 6.0 -- and their launches had 128 blocks: C = 256 at 12x9 on 128 x 32 blocks 14.95 -> 14.77 ms per step;
+        // 64 x 64 and 64 x 32 blocks 15.10 / 14.94; the same for C = 128 via STL_CONV_S8_CO or the wave-specialised kernel: slower)
+        if (shape == 9 && !deep_small) continue;
+        if (deep_small && want_ws && shape != 9) continue;
+        if (want_ws && !getenv("STL_CONV_WS") && shape != 7 && shape != 9) continue;
+        static const char* s0_co = getenv("STL_CONV_S0_CO");   // experiment: output-channel counts that take the 128 px x 64 co 4-wave blocks
+        if (s0_co && atoi(s0_co) == p.Co && p.Ci == p.Co && p.stride == 1 && p.ks == 3 && !p.stuff && !p.wg_partial && !want_ws && shape != 0) continue;
         const int nblk_co = ceil_div(p.Co, sh.co);
         for (int tw = (p.Wo < 4 ? p.Wo : 4); tw <= p.Wo && tw <= sh.px; ++tw)
           for (int frac = 4; frac >= 1; --frac) {
