@@ -1004,7 +1004,9 @@ class Engine:
                         capi.call("stl_stream_create_masked", mask, 8, C.byref(h))
                         pool[key] = (h, h.value)        # lives as long as the process
                     else:
-                        s_ = torch.cuda.Stream(device=self.dev)
+                        # STLPOSE_STREAM_PRIO="p1,p2,p3": HIP priority of side stream 1, 2, 3 (0 normal, -1 high): experiment
+                        pr = [int(v) for v in os.environ.get("STLPOSE_STREAM_PRIO", "").split(",") if v]
+                        s_ = torch.cuda.Stream(device=self.dev, priority=pr[i - 1] if i - 1 < len(pr) else 0)
                         pool[key] = (s_, s_.cuda_stream)
                 self._side.append(pool[key][0])
                 self._stream_arr[i] = pool[key][1]

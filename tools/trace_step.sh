@@ -7,3 +7,4 @@ f=$(ls $OUT/raw/*/*kernel_trace.csv | head -1)
 gzip -c "$f" > $OUT/trace.csv.gz; rm -rf $OUT/raw
 python3 tools/timeline.py $OUT/trace.csv.gz > $OUT/timeline.txt 2>&1
 python3 tools/alone_time.py $OUT/trace.csv.gz 25 > $OUT/alone.txt 2>&1
+python3 tools/chain_gaps.py $OUT/trace.csv.gz 30 all > $OUT/gaps.txt 2>&1
