@@ -41,8 +41,8 @@ def synth_batch(B, H, W, rank, device, sigma=3.0, joints=17):
 
 
 def time_dominant_kernel(ts):
-    """The dominant kernel by GPU time is the 3x3 stride-1 weight gradient `wgrad_ws_kernel<bf16,KS=3,GQ=1>` (BatchNorm
-    backward applied on load; the wave-specialised kernel of round 3).  Since round 3 most of its launches are GROUPED (stl_conv_wgrad_group: up to four
+    """The dominant kernel by GPU time is the 3x3 stride-1 weight gradient `wgrad_kernel<bf16,KS=3,GQ=1>` (BatchNorm
+    backward applied on load; `wgrad_ws_kernel` with STL_WGRAD_WS=1).  Since round 3 most of its launches are GROUPED (stl_conv_wgrad_group: up to four
     weight gradients of one branch per launch).  Every launch of that instantiation in one backward pass -- grouped
     or single -- is timed on its own with HIP events on the launch stream; achieved = algorithmic FLOPs (bytes) of all
     members / sum of durations; the per-launch figures are averages over those launches."""
@@ -78,7 +78,8 @@ def time_dominant_kernel(ts):
     # h, dt and y read once, dw written once (split-K slabs are NOT algorithmic bytes)
     bytes_alg = sum((d.B * d.Hi * d.Wi * d.Ci + 2 * d.B * d.Ho * d.Wo * d.Co) * esz + d.Co * d.Ci * 9 * 4 for _, _, ms in evs for d in ms)
     nconv = sum(len(ms) for _, _, ms in evs)
-    return dict(kernel="wgrad_ws_kernel<bf16,KS=3,GQ=1> (3x3 stride-1 weight gradient, BN-backward on load; grouped launches of up to "
+    return dict(kernel=("wgrad_ws_kernel" if os.environ.get("STL_WGRAD_WS", "0") == "1" else "wgrad_kernel") +
+                       "<bf16,KS=3,GQ=1> (3x3 stride-1 weight gradient, BN-backward on load; grouped launches of up to "
                        f"{max(len(ms) for _, _, ms in evs)} layers of one branch)",
                 launches=len(evs), convs=nconv, ms=tot_ms / len(evs), tflops=flops / tot_ms / 1e9, gbs=bytes_alg / tot_ms / 1e6)
 

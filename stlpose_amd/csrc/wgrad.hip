@@ -215,42 +215,52 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
 
     // unconditional loads (a guarded load would be serialised by the compiler); invalid slots read element 0 and
     // are zeroed when written to LDS
+    // Byte offset of a slot = (tile term: scalar unit) + (slot term: computed once) - wraps * (row-pitch term, one 24-bit mad);
+    // see wgrad_ws_kernel.  Straight-line, no quarter-rate multiplies; the host checks the ranges (dispatch).
+    const int g_cbytes = p.Co * (int)sizeof(T), h_cbytes = p.Ci * (int)sizeof(T);
+    const int g_wrap = -p.Wo * g_cbytes, h_wrap = (p.Hi - k.PI) * p.Wi * h_cbytes;
+    const int n_vp = -vpitch, n_PI = -k.PI;
+    uint32_t g_lo[NVG], h_lo[NVH], slot_ok = 0;
+#pragma unroll
+    for (int i = 0; i < NVG; ++i) {
+        g_lo[i] = (uint32_t)(((g_yx[i] >> 16) * p.Wo + (g_yx[i] & 0xffff)) * g_cbytes + (co0 + g_part * KV) * (int)sizeof(T));
+        if (g_yx[i] >= 0 && g_chok) slot_ok |= 1u << i;
+    }
+#pragma unroll
+    for (int i = 0; i < NVH; ++i) {
+        h_lo[i] = (uint32_t)(((h_rc[i] >> 16) * p.Wi + (h_rc[i] & 0xffff)) * h_cbytes + (ci0 + g_part * KV) * (int)sizeof(T));
+        if (h_rc[i] >= 0 && h_chok) slot_ok |= 1u << (NVG + i);
+    }
     auto fetch = [&](auto SET, int t) __attribute__((always_inline)) {
         constexpr int S = decltype(SET)::value;
-        const int tr = fdiv(t, k.r_tc), tc = t - tr * k.tiles_c;
+        const int tr = sdiv(t, k.m_tc), tc = t - tr * k.tiles_c;
         const int vr0 = tr * p.TH, c0 = tc * p.TW;
-        const int gb0 = fdiv(vr0, k.r_vp), gy0 = vr0 - gb0 * vpitch;
+        const int gb0 = sdiv(vr0, k.m_vp), gy0 = vr0 - gb0 * vpitch;
+        const uint32_t g_t = (uint32_t)(((vr0 - gb0) * p.Wo + c0) * g_cbytes);
         uint32_t ok = 0;
 #pragma unroll
         for (int i = 0; i < NVG; ++i) {
-            int go = -1;
-            if (g_yx[i] >= 0 && g_chok) {
-                int oy = gy0 + (g_yx[i] >> 16), b = gb0;
-                const int c = c0 + (g_yx[i] & 0xffff);
-                { const int wr_ = fdiv(oy, k.r_vp); oy -= wr_ * vpitch, b += wr_; }
-                if (b < p.B && oy < p.Ho && c < p.Wo) go = ((b * p.Ho + oy) * p.Wo + c) * p.Co + co0 + g_part * KV;
-            }
-            const size_t off = go >= 0 ? (size_t)go : 0;
-            ok |= go >= 0 ? 1u << i : 0u;
-            rgv[S][i] = ldg16((const char*)io.g.x + off * sizeof(T));
-            if (GQ) rgq[S][i] = ldg16((const char*)io.g.y + off * sizeof(T));
+            const int oy0 = gy0 + (g_yx[i] >> 16), c = c0 + (g_yx[i] & 0xffff);
+            const int wr_ = fdiv(oy0 < 0 ? 0 : oy0, k.r_vp);
+            const int oy = mad24_vsv(wr_, n_vp, oy0);
+            const bool in = ((slot_ok >> i) & 1u) & (gb0 + wr_ < p.B) & (oy < p.Ho) & (c < p.Wo);
+            const uint32_t off = in ? (uint32_t)mad24_vsv(wr_, g_wrap, (int)(g_t + g_lo[i])) : 0u;
+            ok |= in ? 1u << i : 0u;
+            rgv[S][i] = ldg16((const char*)io.g.x + off);
+            if (GQ) rgq[S][i] = ldg16((const char*)io.g.y + off);
         }
         const int vrs = vr0 * p.stride, cb = c0 * p.stride - k.pad;
-        const int hb0 = fdiv(vrs, k.r_PI), hy0 = vrs - hb0 * k.PI - k.pad;
+        const int hb0 = sdiv(vrs, k.m_PI), hy0 = vrs - hb0 * k.PI - k.pad;
+        const uint32_t h_t = (uint32_t)(((hb0 * p.Hi + hy0) * p.Wi + cb) * h_cbytes);
 #pragma unroll
         for (int i = 0; i < NVH; ++i) {
-            int ho = -1;
-            if (h_rc[i] >= 0 && h_chok) {
-                int iy = hy0 + (h_rc[i] >> 16), b = hb0;
-                const int ix = cb + (h_rc[i] & 0xffff);
-                if (iy >= 0 && ix >= 0 && ix < p.Wi) {
-                    { const int wr_ = fdiv(iy, k.r_PI); iy -= wr_ * k.PI, b += wr_; }
-                    if (b < p.B && iy < p.Hi) ho = ((b * p.Hi + iy) * p.Wi + ix) * p.Ci + ci0 + g_part * KV;
-                }
-            }
-            const size_t off = ho >= 0 ? (size_t)ho : 0;
-            ok |= ho >= 0 ? 1u << (NVG + i) : 0u;
-            rhv[S][i] = ldg16((const char*)io.h.x + off * sizeof(T));
+            const int iy0 = hy0 + (h_rc[i] >> 16), ix = cb + (h_rc[i] & 0xffff);
+            const int wr_ = fdiv(iy0 < 0 ? 0 : iy0, k.r_PI);
+            const int iy = mad24_vsv(wr_, n_PI, iy0);
+            const bool in = ((slot_ok >> (NVG + i)) & 1u) & (iy0 >= 0) & (ix >= 0) & (ix < p.Wi) & (hb0 + wr_ < p.B) & (iy < p.Hi);
+            const uint32_t off = in ? (uint32_t)mad24_vsv(wr_, h_wrap, (int)(h_t + h_lo[i])) : 0u;
+            ok |= in ? 1u << (NVG + i) : 0u;
+            rhv[S][i] = ldg16((const char*)io.h.x + off);
         }
         okm[S] = ok;
     };
@@ -967,6 +977,14 @@ int wgrad_chunk(const stl_wgrad& p) {
 
 template <typename T, int KS>
 int dispatch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
+    {   // both 32-channel kernels address with 24-bit multiplies, scalar-unit division and 32-bit byte offsets
+        const int64_t gpx = (int64_t)k.p.B * k.p.Ho * k.p.Wo, hpx = (int64_t)k.p.B * k.p.Hi * k.p.Wi;
+        const bool small = gpx * k.p.Co * (int64_t)sizeof(T) < ((int64_t)1 << 32) && hpx * k.p.Ci * (int64_t)sizeof(T) < ((int64_t)1 << 32) &&
+                           (int64_t)k.p.Wo * k.p.Co * (int64_t)sizeof(T) < (1 << 23) &&
+                           (int64_t)(k.PI > k.p.Hi ? k.PI - k.p.Hi : k.p.Hi - k.PI) * k.p.Wi * k.p.Ci * (int64_t)sizeof(T) < (1 << 23) &&
+                           k.PI < (1 << 12) && k.tiles_c < (1 << 12) && (int64_t)k.npt * k.p.TH * k.p.stride < (1 << 20);
+        STL_CHECK(small, "wgrad: tensors of 4 GB or more, rows beyond 8 MB or more than 4095 rows / tile columns are not addressable");
+    }
     const int vpx = 32 / ET<T>::KV;
     const int nvh = ceil_div(k.HP * vpx, 256);
     const bool gq = k.p.g.mode == STL_SRC_BNBWD;
@@ -976,17 +994,16 @@ int dispatch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
         }
         return stl_set_error("wgrad: 256-pixel tiles need bf16 and a halo of at most 384 pixels (have %d)", k.HP);
     }
-    if constexpr (KS == 3) {   // wave-specialised kernel (STL_WGRAD_WS, default on): loaders beside MFMA waves, double-buffered LDS
-        static const int ws_env = getenv("STL_WGRAD_WS") ? atoi(getenv("STL_WGRAD_WS")) : 1;
+    if constexpr (KS == 3) {   // wave-specialised kernel (STL_WGRAD_WS, opt-in): loaders beside MFMA waves, double-buffered LDS
+        // STL_WGRAD_WS: 1 = every 3x3 layer, 2 = only the layers of the single-branch tail (>= 200000 pixels, Ci >= 64), default 0.
+        // In one call, three rounds each: 14.68-14.71 / 14.54-14.58 / **14.50-14.54** ms per step -- the wave-specialised kernel is
+        // faster alone (41.9 vs 52.1 us for 28 tiles per block) but holds 134 VGPRs x 8 waves and 100 KB of LDS, one block per CU,
+        // and beside the conv kernels of stages 2-4 that costs more than its tiles gain.  Read per call (tests).
+        const int ws_env = getenv("STL_WGRAD_WS") ? atoi(getenv("STL_WGRAD_WS")) : 0;
         const int nvl = ceil_div(k.HP * vpx, 256);
         const size_t lds_ws = (size_t)k.off_g + 2 * ((size_t)(k.off_h - k.off_g) + (size_t)k.HP * k.psh);
-        // its loaders address with 24-bit multiplies and 32-bit byte offsets
-        const int64_t gpx = (int64_t)k.p.B * k.p.Ho * k.p.Wo, hpx = (int64_t)k.p.B * k.p.Hi * k.p.Wi;
-        const bool small = gpx * k.p.Co * (int64_t)sizeof(T) < ((int64_t)1 << 32) && hpx * k.p.Ci * (int64_t)sizeof(T) < ((int64_t)1 << 32) &&
-                           (int64_t)k.p.Wo * k.p.Co * (int64_t)sizeof(T) < (1 << 23) &&
-                           (int64_t)(k.PI > k.p.Hi ? k.PI - k.p.Hi : k.p.Hi - k.PI) * k.p.Wi * k.p.Ci * (int64_t)sizeof(T) < (1 << 23) &&
-                           k.PI < (1 << 12) && k.tiles_c < (1 << 12) && (int64_t)k.npt * k.p.TH * k.p.stride < (1 << 20);
-        if (ws_env && small && lds_ws <= 150 * 1024) {
+        const bool tail_like = (int64_t)k.p.B * k.p.Ho * k.p.Wo >= 200000 && k.p.Ci >= 64;
+        if (ws_env && lds_ws <= 150 * 1024 && (ws_env != 2 || tail_like)) {
             if (nvl <= 3) return gq ? launch_ws<T, KS, 3, true>(k, grid, lds_ws, st) : launch_ws<T, KS, 3, false>(k, grid, lds_ws, st);
             if (nvl <= 6) return gq ? launch_ws<T, KS, 6, true>(k, grid, lds_ws, st) : launch_ws<T, KS, 6, false>(k, grid, lds_ws, st);
             if (nvl <= 9) return gq ? launch_ws<T, KS, 9, true>(k, grid, lds_ws, st) : launch_ws<T, KS, 9, false>(k, grid, lds_ws, st);   // stride 2: 33 x 17 halo

@@ -1085,14 +1085,17 @@ class Engine:
                 self._optim_descs.append(w)
 
         nxt = dict(at)
+        # STLPOSE_OPTIM_STREAM: stream of the optimiser ops; default = the stream of the later bucket's reductions; the last
+        # branch stream is the least loaded queue of the plan (busy 4.4 of 15 ms) and idle in the single-branch tail
+        fixed = os.environ.get("STLPOSE_OPTIM_STREAM", "")
         for idx, op in enumerate(ops):
             new_ops.append(op)
             if idx in nxt:
                 if prev is not None:
-                    emit(prev, op[2])
+                    emit(prev, int(fixed) if fixed else op[2])
                 prev = nxt[idx]
         if prev is not None:
-            emit(prev, ops[self.buckets[prev]["op"]][2])
+            emit(prev, int(fixed) if fixed else ops[self.buckets[prev]["op"]][2])
         self.bwd_ops_opt = new_ops
 
     def bucket_wait(self, i: int, stream: int):

@@ -105,7 +105,7 @@ def test_conv_forward_plain_and_stats(case, dt, tile):
     assert torch.allclose(sums[1], (stored * stored).sum(0), rtol=1e-5, atol=1e-3)
 
 
-@pytest.mark.parametrize("wtile", [128, 256, "wide128", "wide256"])
+@pytest.mark.parametrize("wtile", [128, 256, "wide128", "wide256", "ws128"])
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(2, 24, 16, 32, 32, 3, 1), (2, 24, 18, 32, 64, 3, 2), (2, 8, 6, 128, 64, 1, 1),
                                   (4, 48, 36, 64, 64, 3, 1), (4, 24, 18, 128, 128, 3, 1), (2, 24, 18, 64, 256, 1, 1),
@@ -116,6 +116,11 @@ def test_conv_bn_relu_chain_forward_backward(case, dt, wtile, monkeypatch):
     batch_norm(train) -> relu -> conv2d -> batch_norm(train)."""
     code, td, tol = DT[dt]
     B, H, W, Ci, Co, ks, s = case
+    if wtile == "ws128":   # opt-in wave-specialised weight gradient (wgrad_ws_kernel: 3x3 only, falls back elsewhere)
+        if ks != 3:
+            pytest.skip("the wave-specialised weight gradient is 3x3 only")
+        monkeypatch.setenv("STL_WGRAD_WS", "1")
+        wtile = 128
     wide = isinstance(wtile, str)   # opt-in 64x64-channel weight-gradient variant
     if wide:
         wtile = int(wtile[4:])
@@ -551,13 +556,17 @@ def test_gaussian_targets_match_reference_golden(golden_dir):
         assert np.array_equal(tgt.cpu().numpy() > 0, g[f"{tag}_target"] > 0)
 
 
+@pytest.mark.parametrize("ws", ["0", "1"])
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(2, 24, 16, 32, 32, 3, 1, 3), (3, 12, 9, 64, 64, 3, 1, 4), (2, 24, 18, 32, 64, 3, 2, 2), (2, 12, 9, 128, 32, 1, 1, 8)])
-def test_wgrad_group_equals_single_launches(case, dt):
+def test_wgrad_group_equals_single_launches(case, dt, ws, monkeypatch):
     """stl_conv_wgrad_group (several weight gradients of one shape in ONE launch, grid.x = n * nsplit) against n
     stl_conv_wgrad launches on the same tensors: every block does the same work in the same order -> bit-identical
     slabs.  Sources: BN (+ReLU) on h and BatchNorm-backward on g, like the layers the planner groups."""
     B, H, W, Ci, Co, ks, s, n = case
+    if ws == "1" and ks != 3:
+        pytest.skip("the wave-specialised weight gradient is 3x3 only")
+    monkeypatch.setenv("STL_WGRAD_WS", ws)   # uniform 8-wave kernel (default) / wave-specialised kernel
     code, td, _ = DT[dt]
     pad = 1 if ks == 3 else 0
     Ho, Wo = (H + 2 * pad - ks) // s + 1, (W + 2 * pad - ks) // s + 1

@@ -25,7 +25,7 @@ def main():
     write_kb = last_wgrads(wd, "WRITE_SIZE", n)
     fetch_b = 2.0 * 1024.0 * sum(fetch_kb) / n   # gfx950 correction: x2
     write_b = 1024.0 * sum(write_kb) / n
-    res = dict(kernel="wgrad_ws_kernel<bf16,KS=3,GQ=1> (3x3 stride-1, BN-backward on load)", launches=n,
+    res = dict(kernel="wgrad_kernel / wgrad_ws_kernel <bf16,KS=3,GQ=1> (3x3 stride-1, BN-backward on load)", launches=n,
                fetch_size_raw_kb_per_launch=sum(fetch_kb) / n, write_size_raw_kb_per_launch=sum(write_kb) / n,
                fetch_bytes_per_launch=fetch_b, write_bytes_per_launch=write_b, traffic_bytes_per_launch=fetch_b + write_b,
                fused_bwd=os.environ.get("STLPOSE_FUSED_BWD", "0"), wgrad_group=os.environ.get("STLPOSE_WGRAD_GROUP", "4"),
