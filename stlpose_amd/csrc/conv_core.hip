@@ -707,7 +707,12 @@ int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStrea
             if (nva <= 6) return launch<T, KS, 8, 1, 4, 2, 6, Q, PE>(k, grid, lds, st);
             break;
         case 2:
-            if (nva <= 3) return launch<T, KS, 4, 2, 4, 2, 3, Q, PE>(k, grid, lds, st);
+#ifndef STL_S2Q_OCC
+#define STL_S2Q_OCC 1   // waves per SIMD the register budget of the 256 px x 64 co DATA-GRADIENT kernel is sized for (1: up to 256 VGPRs, one block owns
+                        // the CU; 3 = 168 VGPRs + 49 spilled, 4 = 128 + 160 spilled: 15.6 / 18.2 vs 14.64 ms per step -- leaving room for other
+                        // kernels' waves needs a smaller per-wave tile, not a register cap)
+#endif
+            if (nva <= 3) return launch<T, KS, 4, 2, 4, 2, 3, Q, PE, (Q ? STL_S2Q_OCC : 1)>(k, grid, lds, st);
             break;
         case 3:
             if (nva <= 3) return launch<T, KS, 4, 2, 4, 4, 3, Q, PE>(k, grid, lds, st);
