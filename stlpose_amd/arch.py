@@ -53,9 +53,19 @@ def walk(g, a: Arch):
         r = g.conv_bn(f"{p}.downsample.0", f"{p}.downsample.1", x, 256, 1, 1, False) if i == 0 else x
         x = g.fuse([(h, 0), (r, 0)], relu=True)
     # transition1 (HRnet.py:341-380, 443-447)
+    # the two transition convolutions read the same 113 MB tensor and ran back to back, alone on the chip (57 + 71 us): the
+    # second one (and its materialised output, branch 1's input) can go to branch 1's stream (opt-in STLPOSE_SPLIT_TRANSITION1=1; measured 14.55-14.61 vs 14.54-14.56 ms per step: both are bandwidth-bound)
+    import os
+    split = os.environ.get("STLPOSE_SPLIT_TRANSITION1", "0") != "0" and getattr(g, "nstreams", 1) > 1
     t0 = g.conv_bn("transition1.0.0", "transition1.0.1", x, w[0], 3, 1, True)
+    y0 = g.fuse([(t0, 0)], relu=False)
+    if split:
+        g.set_stream(1)
     t1 = g.conv_bn("transition1.1.0.0", "transition1.1.0.1", x, w[1], 3, 2, True)
-    ys = [g.fuse([(t0, 0)], relu=False), g.fuse([(t1, 0)], relu=False)]
+    y1 = g.fuse([(t1, 0)], relu=False)
+    if split:
+        g.set_stream(0)
+    ys = [y0, y1]
     for stage, nbr in ((2, 2), (3, 3), (4, 4)):
         nmod = a.modules[stage - 2]
         for m in range(nmod):
