@@ -144,3 +144,18 @@ def test_torch_library_ops_are_registered_and_gpu_only():
         assert idx.shape == (2, 17) and mx.shape == (2, 17, 1) and preds.shape == (2, 17, 2)
         loss, dout = torch.ops.stlpose.person_mse(hm, hm, torch.empty(2, 17, 1, device="cuda"), 1.0)
         assert loss.shape == () and dout.shape == hm.shape
+
+
+def test_scalar_magic_division_is_exact_in_the_checked_range():
+    """csrc `sdiv(n, m)` = (n * ceil(2^32 / d)) >> 32 replaces n / d on the scalar unit (conv_core.hip, wgrad.hip) for tile
+    decoding.  The hosts check d < 2^11 (conv: tiles per row, virtual row pitches) resp. d < 2^12 (weight gradient) and
+    n < 2^21 resp. 2^20: exactness needs n * (m * d - 2^32) < 2^32, which those ranges imply (m * d - 2^32 < d)."""
+    rng = np.random.default_rng(0)
+    for dmax, nmax in ((1 << 11, 1 << 21), (1 << 12, 1 << 20)):
+        ds = np.unique(np.concatenate([np.arange(1, 64), rng.integers(1, dmax, 400), [dmax - 1]])).astype(np.uint64)
+        for d in ds:
+            m = (np.uint64(1 << 32) + d - np.uint64(1)) // d
+            n = np.unique(np.concatenate([np.arange(0, 4096), rng.integers(0, nmax, 4000), [nmax - 1],
+                                          (np.arange(1, 300) * int(d)) % nmax, (np.arange(1, 300) * int(d) - 1) % nmax])).astype(np.uint64)
+            q = (n * m) >> np.uint64(32)
+            assert np.array_equal(q, n // d), f"d={int(d)}"

@@ -408,6 +408,16 @@ def test_error_reporting():
     p.dtype, p.ks, p.stride = 0, 5, 1
     with pytest.raises(RuntimeError, match="ks must be 1 or 3"):
         capi.call("stl_conv_forward", C.byref(p), stream())
+    # round 3: the address arithmetic works with 24-bit multiplies and scalar-unit division; problems beyond its range must be
+    # refused with a message, never mis-addressed (no memory is touched before the check: the pointers stay null)
+    q = capi.Conv()
+    q.dtype, q.ks, q.stride = capi.BF16, 3, 1
+    q.B, q.Hi, q.Wi, q.Ci, q.Ho, q.Wo, q.Co = 8, 1500, 1500, 32, 1500, 1500, 32   # 1.8e7 pixels (>= 2^24), 5.8e8 elements (< 2^31)
+    q.TH, q.TW, q.shape = 0, 0, -1
+    dummy = torch.zeros(64, device="cuda")   # never dereferenced: the range check precedes the launch
+    q.src.x, q.w, q.out = dummy.data_ptr(), dummy.data_ptr(), dummy.data_ptr()
+    with pytest.raises(RuntimeError, match="not addressable|exceeds the fast-division limits|scalar-division limits"):
+        capi.call("stl_conv_forward", C.byref(q), stream())
 
 
 def test_weight_prep_and_reduce_slabs_tables():
