@@ -56,3 +56,25 @@ print(f"backward program: {len(ops)} ops on {len(pers)} streams; sum of start de
 print("by op kind (ms):", {k: round(v / 1e3, 2) for k, v in byk.most_common()})
 for d, i in big:
     print(f"delay {d:6.1f} us  start {start[i]:8.1f}  {nm(i)}  waits {[(w, 's%d' % ops[w][2], round(end[w], 1)) for w in waits[i]]}")
+
+# Hypothesis check: does a cross-stream wait release when the producer OP ends, or when everything the producer STREAM had been
+# given before the consumer was issued has ended?  alt_ready = max(end of the stream predecessor, for every waited stream t the
+# end of the LAST op of t with a smaller index than the consumer).
+if len(sys.argv) > 3:
+    last_before = {}
+    n_hit = n_tot = 0; resid_a = resid_b = 0.0
+    for i, o in enumerate(ops):
+        s = o[2]
+        if waits[i]:
+            deps_true = [end[w] for w in waits[i]] + ([end[pp]] if (pp := max((j for j in pers[s] if j < i), default=None)) is not None else [])
+            alt = list(deps_true)
+            for w in waits[i]:
+                t = ops[w][2]
+                j = max(j for j in pers[t] if j < i)
+                alt.append(end[j])
+            d_true, d_alt = start[i] - max(deps_true), start[i] - max(alt)
+            n_tot += 1
+            if d_true > 25:
+                n_hit += 1; resid_a += d_true; resid_b += max(d_alt, 0.0)
+                print(f"#{i} s{s} start {start[i]:8.1f}  delay vs waited ops {d_true:6.1f}  vs everything queued on their streams before it {d_alt:6.1f}")
+    print(f"{n_hit} delayed ops with waits: summed delay {resid_a / 1e3:.2f} ms against the waited ops, {resid_b / 1e3:.2f} ms against the alternative")
