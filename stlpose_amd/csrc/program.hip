@@ -54,7 +54,9 @@ extern "C" int stl_program_create(const stl_op* ops, int n, int nstreams, void**
             }
         if (o.record) {
             hipEvent_t e;
-            if (hipEventCreateWithFlags(&e, event_flags()) != hipSuccess) {
+            // gradient-bucket ends are picked up from OUTSIDE the program (stl_program_wait_op: the communication stream of a
+            // data-parallel run, whose collective may hand the bucket to other devices): those few keep the system-scope fence
+            if (hipEventCreateWithFlags(&e, o.kind == STL_OP_BN_GRADS_RANGE ? (unsigned)hipEventDisableTiming : event_flags()) != hipSuccess) {
                 delete p;
                 return stl_set_error("program_create: hipEventCreate failed");
             }
