@@ -159,3 +159,55 @@ def test_scalar_magic_division_is_exact_in_the_checked_range():
                                           (np.arange(1, 300) * int(d)) % nmax, (np.arange(1, 300) * int(d) - 1) % nmax])).astype(np.uint64)
             q = (n * m) >> np.uint64(32)
             assert np.array_equal(q, n // d), f"d={int(d)}"
+
+
+def test_in_program_optimizer_ops_are_ordered_behind_the_last_readers(monkeypatch):
+    """engine.attach_optimizer (STLPOSE_FUSED_OPTIM=1): the optimiser slice of a gradient bucket may run only when (a) the bucket's
+    reductions are done and (b) every data gradient that still reads the bucket's weights / BatchNorm parameters has run -- the
+    ("wuse", layer) tokens.  Checked on the planned op list (no GPU): one optimiser op per bucket, placed behind the bucket's own
+    reductions, waiting for a token of every convolution in the bucket that has a data gradient; the weight re-layout follows its
+    optimiser op; the scheduler turns the tokens into waits on the right producers."""
+    monkeypatch.setenv("STLPOSE_BUCKET_MB", "8")
+    from stlpose_amd import PoseHighResolutionNet, capi
+    from stlpose_amd.engine import Engine
+    m = PoseHighResolutionNet("w32", "bf16")
+    m._pack(torch.device("cpu"))
+    e = Engine(m.arch, m._store, 2, 128, 96, capi.BF16, True)
+    e.attach_optimizer(0, 1 << 20, 2 << 20, 3 << 20, 4 << 20, 5 << 20, 6 << 20)   # dummy addresses: nothing is launched
+    ops = e.bwd_ops_opt
+    names = [o[0] for o in ops]
+    nb = len(e.buckets)
+    assert nb >= 8 and names.count("stl_optim_slice") == nb
+    assert [o for o in ops if o[0] not in ("stl_optim_slice", "stl_wprep_range")] == list(e.bwd_ops)   # the backward ops themselves are untouched
+    pos_bn = {i: next(k for k, o in enumerate(ops) if o[1] is b["br"]) for i, b in enumerate(e.buckets)}
+    producers = {}
+    for k, o in enumerate(ops):
+        for w in o[4]:
+            if isinstance(w, tuple) and w[0] == "wuse":
+                producers[w] = k
+    dgrad_layers = {w[1] for w in producers}
+    covered = 0
+    for k, o in enumerate(ops):
+        if o[0] != "stl_optim_slice":
+            continue
+        i = next(r[1] for r in o[3] if isinstance(r, tuple) and r[0] == "bucketbn")
+        b = e.buckets[i]
+        assert k > pos_bn[i], "optimiser slice in front of its bucket's reductions"
+        assert o[1].n == b["hi"] - b["lo"] and o[1].p == (1 << 20) + 4 * b["lo"]
+        toks = {r for r in o[3] if isinstance(r, tuple) and r[0] == "wuse"}
+        want = {("wuse", c.master_off) for c in e.convs if b["lo"] <= c.master_off < b["hi"] and c.master_off in dgrad_layers}
+        assert toks == want and all(producers[t] < k for t in toks)
+        covered += len(toks)
+        nxt = ops[k + 1]
+        if nxt[0] == "stl_wprep_range":
+            assert ("optim", i) in nxt[3] and nxt[2] == o[2]
+    assert covered == len(dgrad_layers) == sum(1 for o in e.bwd_ops if o[0] == "stl_conv_forward")
+    waits, need = e._schedule(ops)
+    for k, o in enumerate(ops):
+        if o[0] == "stl_optim_slice":
+            for t in (r for r in o[3] if isinstance(r, tuple) and r[0] == "wuse"):
+                j = producers[t]
+                same = ops[j][2] == o[2]
+                direct = any(ops[w][2] == ops[j][2] and w >= j for w in waits[k])
+                earlier = any(ops[w][2] == ops[j][2] and w >= j for kk in range(k) if ops[kk][2] == o[2] for w in waits[kk])
+                assert same or direct or earlier, (k, t)
