@@ -625,6 +625,15 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* partials
         const float* src = partials + e.part_off + j;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         int k = 0;
+        // eight slabs in flight, added in slab order (same sums as four at a time, half the dependent memory round trips: the
+        // bucket that closes the step sums 125 slabs per element on 110 blocks, alone on the chip)
+        for (; k + 8 <= e.nsplit; k += 8) {
+            float4 a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const float4*>(src + (int64_t)(k + u) * slab);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s.x += a[u].x, s.y += a[u].y, s.z += a[u].z, s.w += a[u].w;
+        }
         for (; k + 4 <= e.nsplit; k += 4) {
             const float4 a0 = *reinterpret_cast<const float4*>(src + (int64_t)(k + 0) * slab);
             const float4 a1 = *reinterpret_cast<const float4*>(src + (int64_t)(k + 1) * slab);
