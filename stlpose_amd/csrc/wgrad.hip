@@ -953,7 +953,7 @@ int dispatch64(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
 // launch grid + block-order fields of k (wg_block): XCD-aware order when there is more than one channel chunk
 // (STL_WGRAD_XCD=0: plain 3-D grid)
 dim3 wg_grid(WgK& k, int units, int gy, int gz) {
-    static const int xcd_env = getenv("STL_WGRAD_XCD") ? atoi(getenv("STL_WGRAD_XCD")) : 1;
+    const int xcd_env = getenv("STL_WGRAD_XCD") ? atoi(getenv("STL_WGRAD_XCD")) : 1;   // read per call (tests cover both orders)
     k.units = units, k.gy = gy, k.gz = gz;
     k.xmap = xcd_env && gy * gz > 1;
     if (!k.xmap) return dim3(units, gy, gz);

@@ -566,7 +566,7 @@ def test_gaussian_targets_match_reference_golden(golden_dir):
         assert np.array_equal(tgt.cpu().numpy() > 0, g[f"{tag}_target"] > 0)
 
 
-@pytest.mark.parametrize("ws", ["0", "1"])
+@pytest.mark.parametrize("ws", ["0", "1", "0-plain-grid"])
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(2, 24, 16, 32, 32, 3, 1, 3), (3, 12, 9, 64, 64, 3, 1, 4), (2, 24, 18, 32, 64, 3, 2, 2), (2, 12, 9, 128, 32, 1, 1, 8)])
 def test_wgrad_group_equals_single_launches(case, dt, ws, monkeypatch):
@@ -576,7 +576,8 @@ def test_wgrad_group_equals_single_launches(case, dt, ws, monkeypatch):
     B, H, W, Ci, Co, ks, s, n = case
     if ws == "1" and ks != 3:
         pytest.skip("the wave-specialised weight gradient is 3x3 only")
-    monkeypatch.setenv("STL_WGRAD_WS", ws)   # uniform 8-wave kernel (default) / wave-specialised kernel
+    monkeypatch.setenv("STL_WGRAD_WS", ws[0])   # uniform 8-wave kernel (default) / wave-specialised kernel
+    monkeypatch.setenv("STL_WGRAD_XCD", "0" if ws.endswith("plain-grid") else "1")   # XCD-aware block order (default) / plain 3-D grid
     code, td, _ = DT[dt]
     pad = 1 if ks == 3 else 0
     Ho, Wo = (H + 2 * pad - ks) // s + 1, (W + 2 * pad - ks) // s + 1
