@@ -78,8 +78,7 @@ def time_dominant_kernel(ts):
     # h, dt and y read once, dw written once (split-K slabs are NOT algorithmic bytes)
     bytes_alg = sum((d.B * d.Hi * d.Wi * d.Ci + 2 * d.B * d.Ho * d.Wo * d.Co) * esz + d.Co * d.Ci * 9 * 4 for _, _, ms in evs for d in ms)
     nconv = sum(len(ms) for _, _, ms in evs)
-    return dict(kernel=("wgrad_ws_kernel" if os.environ.get("STL_WGRAD_WS", "0") == "1" else "wgrad_kernel") +
-                       "<bf16,KS=3,GQ=1> (3x3 stride-1 weight gradient, BN-backward on load; grouped launches of up to "
+    return dict(kernel="wgrad_kernel<bf16,KS=3,GQ=1> (3x3 stride-1 weight gradient, BN-backward on load; grouped launches of up to "
                        f"{max(len(ms) for _, _, ms in evs)} layers of one branch)",
                 launches=len(evs), convs=nconv, ms=tot_ms / len(evs), tflops=flops / tot_ms / 1e9, gbs=bytes_alg / tot_ms / 1e6)
 
@@ -411,10 +410,6 @@ def main():
 
     import contextlib
     ctx = contextlib.nullcontext()
-    if os.environ.get("STLPOSE_MAIN_PRIO"):   # experiment: the main (branch-0 / critical chain) stream at another priority
-        hp = torch.cuda.Stream(device=dev, priority=int(os.environ["STLPOSE_MAIN_PRIO"]))
-        hp.wait_stream(torch.cuda.current_stream(dev))
-        ctx = torch.cuda.stream(hp)
     with ctx:
         for _ in range(a.warmup):
             ts.step()
@@ -483,7 +478,6 @@ def main():
                 try:
                     rec = json.load(open(f))
                     if rec.get("launches") == dom["launches"] and (a.arch, a.height, a.width, a.batch, a.dtype) == ("w32", 384, 288, 32, "bf16") \
-                            and rec.get("fused_bwd", "0") == os.environ.get("STLPOSE_FUSED_BWD", "0") \
                             and rec.get("wgrad_group", "1") == os.environ.get("STLPOSE_WGRAD_GROUP", "4"):
                         traffic, traffic_src = round(rec["traffic_bytes_per_launch"]), "profiles/" + os.path.basename(f)
                 except Exception:

@@ -81,20 +81,8 @@ typedef struct stl_conv {
                               z <= 0).  With addend / mask_y (mask_bn.relu = 0) / red this is the backward of a
                               residual block end  z = ReLU(BN(y) + x)  fused into the data gradient that
                               produces the last contribution to dz (HRnet.py:58-59,99-100). */
-    /* Fused backward of a 3x3 stride-1 C -> C convolution (aten::convolution_backward, data AND weight part in
-     * one launch): when wg_partial != NULL this call is the data gradient described above (src = BNBWD gradient
-     * of the conv's output, w = transposed filters) and ALSO accumulates the weight gradient
-     * dw[co][tap][ci] = sum_pixels g[pixel][co] * wg_h(pixel + tap - 1)[ci] from the same staged tiles into
-     * wg_partial[s][C][9][C] (fp32, s < wg_nsplit split-K slabs, summed later by stl_reduce_slabs).
-     * Requires ks 3, stride 1, stuff 0, Ci == Co == C, C % 32 == 0, C <= 64, src.mode BNBWD;
-     * wg_nsplit = number of pixel groups (grid = wg_nsplit * C/32 blocks), a multiple of 8. */
-    stl_src wg_h;          /* the conv's forward input (PLAIN or BN source), [B,Ho,Wo,C]     */
-    float* wg_partial;     /* [wg_nsplit][C][9][C] or NULL                                  */
-    int32_t wg_nsplit;
     void* src_out;         /* BNADD source: [B,Hi,Wi,Ci] dtype -- the transformed source (the block-end sum) is stored here, every
                               pixel by the one block whose tile owns it; NULL = not stored */
-    int32_t grid_pct;      /* 0 / 100: default persistent-grid size; else per cent of it (the planner shrinks the grids of
-                              launches that run beside other branches' launches: they share the CUs instead of queueing) */
 } stl_conv;
 int stl_conv_forward(const stl_conv* p, void* stream);
 /* Fill p->shape / p->TH / p->TW once (host-side tile search) so that launches are cheap. */
@@ -331,20 +319,16 @@ int stl_program_destroy(void* program);
  * communication stream picks up a finished gradient bucket. */
 int stl_program_wait_op(void* program, int op, void* stream);
 
-/* Streams restricted to a set of compute units (hipExtStreamCreateWithCUMask): mask bit i = CU i of the driver's
- * enumeration.  The reference runs the branches of an exchange module one after the other (HRnet.py:252-253) and
- * leaves the overlap of the weight gradients with the data-gradient chain to cuDNN / the autograd engine; here the
- * planner places them explicitly, and a masked stream bounds the share of the chip the off-chain work may take. */
-int stl_stream_create_masked(const uint32_t* mask, int nwords, void** out_stream);
-int stl_stream_destroy(void* stream);
-/* Debug: out[2b] = XCC id, out[2b+1] = HW_ID register of block b (64 threads, spins spin_ticks of the 100 MHz clock). */
-int stl_probe_placement(uint32_t* out, int nblocks, int spin_ticks, void* stream);
-
 /* Self-checks that need no reference: MFMA / LDS-transpose lane maps (used by tests). */
 int stl_selftest_mfma(float* out /* [4] max abs err: bf16 mfma, f32 mfma, tr-read, f64 atomic */, void* stream);
 
 const char* stl_last_error(void);
 int stl_version(void);
+/* Hash (16 hex digits) of the kernel and header sources this library was compiled from (stlpose_amd/build.py). */
+const char* stl_build_id(void);
+/* Name of the kernel instantiation the calling thread launched last, e.g. "conv_core_kernel<bf16,3,4,2,4,2,3,1,0,1,-1,0>"
+ * (template arguments in declaration order) -- measurement only: bench.py groups per-launch timings by it. */
+const char* stl_last_kernel(void);
 
 #ifdef __cplusplus
 }

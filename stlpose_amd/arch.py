@@ -53,18 +53,12 @@ def walk(g, a: Arch):
         r = g.conv_bn(f"{p}.downsample.0", f"{p}.downsample.1", x, 256, 1, 1, False) if i == 0 else x
         x = g.fuse([(h, 0), (r, 0)], relu=True)
     # transition1 (HRnet.py:341-380, 443-447)
-    # the two transition convolutions read the same 113 MB tensor and ran back to back, alone on the chip (57 + 71 us): the
-    # second one (and its materialised output, branch 1's input) can go to branch 1's stream (opt-in STLPOSE_SPLIT_TRANSITION1=1; measured 14.55-14.61 vs 14.54-14.56 ms per step: both are bandwidth-bound)
-    import os
-    split = os.environ.get("STLPOSE_SPLIT_TRANSITION1", "0") != "0" and getattr(g, "nstreams", 1) > 1
+    # (the two transition convolutions read the same 113 MB tensor back to back; putting the second on branch 1's stream
+    # measured 14.55-14.61 vs 14.54-14.56 ms per step in round 3 -- both are bandwidth-bound -- and was dropped)
     t0 = g.conv_bn("transition1.0.0", "transition1.0.1", x, w[0], 3, 1, True)
     y0 = g.fuse([(t0, 0)], relu=False)
-    if split:
-        g.set_stream(1)
     t1 = g.conv_bn("transition1.1.0.0", "transition1.1.0.1", x, w[1], 3, 2, True)
     y1 = g.fuse([(t1, 0)], relu=False)
-    if split:
-        g.set_stream(0)
     ys = [y0, y1]
     for stage, nbr in ((2, 2), (3, 3), (4, 4)):
         nmod = a.modules[stage - 2]
@@ -94,33 +88,17 @@ def _exchange_module(g, p: str, xs: List, widths: Sequence[int], nblocks: int, f
             x = g.fuse([(h, 0), (x, 0)], relu=True)
         xs[b] = x
     outs = []
-    # Exchange: out_i = ReLU(sum_j f_ij(x_j)).  The f_ij chains of one module are independent of each other, so they
-    # are spread over the branch streams by estimated cost (emission order -- and with it the state_dict order --
-    # is untouched): on "stream i for everything that feeds out_i" the deepest output serialises up to six
-    # stride-2 convolutions (0->3: 3 hops, 1->3: 2, 2->3: 1) while the other queues idle.
-    ns = max(n, getattr(g, "nstreams", n))   # streams without a branch in this stage are idle: use them too
-    load = [0.0] * ns
-    balance = getattr(g, "balance_exchange", False)
+    # Exchange: out_i = ReLU(sum_j f_ij(x_j)): everything that feeds out_i runs on stream i.  (Spreading the f_ij chains over
+    # the streams by estimated cost measured 18.4 -> 18.8 ms per step in round 2: every moved chain pays a cross-stream event
+    # wait at both ends, more than the serialisation it removes.)
     for i in range(n if full else 1):
         terms = []
+        g.set_stream(i)
         for j in range(n):
             q = f"{p}.fuse_layers.{i}.{j}"
             if j == i:
                 terms.append((xs[j], 0))
-                continue
-            strm = i
-            if balance:
-                cost, t, c_in = 0.0, xs[j], None
-                if j > i:
-                    cost = g.est_cost(xs[j], widths[i], 1, 1)
-                else:
-                    for k in range(i - j):
-                        last = k == i - j - 1
-                        cost += g.est_cost(xs[j], widths[i] if last else widths[j], 3, 2, hop=k)
-                strm = min(range(ns), key=lambda s_: (load[s_], s_ != i))
-                load[strm] += cost
-            g.set_stream(strm)
-            if j > i:  # 1x1 conv + BN, nearest-upsampled 2^(j-i) inside the sum kernel
+            elif j > i:  # 1x1 conv + BN, nearest-upsampled 2^(j-i) inside the sum kernel
                 terms.append((g.conv_bn(f"{q}.0", f"{q}.1", xs[j], widths[i], 1, 1, False), j - i))
             else:        # (i-j) stride-2 3x3 hops, ReLU after all but the last
                 t = xs[j]
@@ -128,7 +106,6 @@ def _exchange_module(g, p: str, xs: List, widths: Sequence[int], nblocks: int, f
                     last = k == i - j - 1
                     t = g.conv_bn(f"{q}.{k}.0", f"{q}.{k}.1", t, widths[i] if last else widths[j], 3, 2, not last)
                 terms.append((t, 0))
-        g.set_stream(i)
         outs.append(g.fuse(terms, relu=True))
     g.set_stream(0)
     return outs

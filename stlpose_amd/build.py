@@ -1,6 +1,8 @@
 """Build libstlpose_hip.so (gfx950) in-tree with hipcc.  `python -m stlpose_amd.build`."""
 from __future__ import annotations
 
+import glob
+import hashlib
 import os
 import subprocess
 import sys
@@ -8,10 +10,29 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(HERE, "..", "include")
 LIB = os.path.join(HERE, "libstlpose_hip.so")
-SOURCES = ["capi.hip", "conv_core.hip", "wgrad.hip", "elementwise.hip", "program.hip"]
+# (source, object tag, extra flags): conv_core and wgrad are compiled once per dtype (-DSTL_DT) so that their kernel
+# instantiations build in parallel
+UNITS = [("capi.hip", "capi", []), ("conv_core.hip", "conv_core_bf16", ["-DSTL_DT=1"]), ("conv_core.hip", "conv_core_f32", ["-DSTL_DT=0"]),
+         ("wgrad.hip", "wgrad_bf16", ["-DSTL_DT=1"]), ("wgrad.hip", "wgrad_f32", ["-DSTL_DT=0"]), ("elementwise.hip", "elementwise", []),
+         ("program.hip", "program", [])]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value"]
+
+
+def source_files():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(CSRC, "*.cuh"))
+                  + glob.glob(os.path.join(INCLUDE, "*.h")))
+
+
+def source_id() -> str:
+    """16 hex digits over names and contents of csrc/* and include/*: what stl_build_id() of a current library returns."""
+    h = hashlib.sha256()
+    for f in source_files():
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _stale(target: str, deps) -> bool:
@@ -27,14 +48,18 @@ def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> st
     library never carries them: see the note at STAMP() in conv_core.hip."""
     lib = LIB.replace(".so", "_stamps.so") if stamps else LIB
     suffix, extra = (".stamps.o", ["-DSTL_STAMPS"]) if stamps else (".o", [])
-    hdrs = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "conv_common.inc"), os.path.join(CSRC, "conv_ws.inc"), os.path.join(CSRC, "conv1x1.inc"),
-            os.path.join(HERE, "..", "include", "stlpose_hip.h")]
+    srcs = source_files()
+    sid = source_id()
     objs, jobs = [], []
-    for s in SOURCES:
-        src, obj = os.path.join(CSRC, s), os.path.join(CSRC, s.replace(".hip", suffix))
+    for s, tag, fl in UNITS:
+        src, obj = os.path.join(CSRC, s), os.path.join(CSRC, tag + suffix)
         objs.append(obj)
-        if force or _stale(obj, [src] + hdrs):
-            jobs.append([HIPCC, *FLAGS, *extra, "-c", src, "-o", obj])
+        # capi carries the build id, i.e. depends on every source; the others on their file and the shared headers / includes
+        deps = srcs if tag == "capi" else [src] + [f for f in srcs if not f.endswith(".hip")]
+        if tag == "capi":
+            fl = fl + [f'-DSTL_BUILD_ID="{sid}"']
+        if force or _stale(obj, deps):
+            jobs.append([HIPCC, *FLAGS, *extra, *fl, "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -44,10 +69,12 @@ def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> st
             raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(lib, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+    if verbose:
+        print("build id", sid)
     return lib
 
 

@@ -28,7 +28,7 @@ class Conv(C.Structure):
                 ("Co", i32), ("ks", i32), ("stride", i32), ("stuff", i32), ("TH", i32), ("TW", i32), ("shape", i32),
                 ("src", Src), ("w", vp), ("out", vp), ("bias", vp), ("out_relu", i32), ("out_stats", vp),
                 ("addend", vp), ("mask_y", vp), ("mask_bn", Src), ("red", vp), ("mask_z", vp),
-                ("wg_h", Src), ("partial", vp), ("wg_nsplit", i32), ("src_out", vp), ("grid_pct", i32)]   # `partial` = wg_partial (fused weight gradient slabs)
+                ("src_out", vp)]
 
 
 class Wgrad(C.Structure):
@@ -160,11 +160,10 @@ SIGNATURES = {
     "stl_program_destroy": [vp],
     "stl_program_wait_op": [vp, i32, vp],
     "stl_selftest_mfma": [vp, vp],
-    "stl_stream_create_masked": [vp, i32, C.POINTER(vp)],
-    "stl_stream_destroy": [vp],
-    "stl_probe_placement": [vp, i32, i32, vp],
     "stl_version": [],
 }
+
+STRING_FUNCS = ("stl_last_error", "stl_build_id", "stl_last_kernel")   # const char* f(void)
 
 _lib = None
 
@@ -182,8 +181,10 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)  # AttributeError if the ABI and this table disagree
             fn.argtypes = args
             fn.restype = C.c_int
-        l.stl_last_error.argtypes = []
-        l.stl_last_error.restype = C.c_char_p
+        for name in STRING_FUNCS:
+            fn = getattr(l, name)
+            fn.argtypes = []
+            fn.restype = C.c_char_p
         _lib = l
     return _lib
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <initializer_list>
 #include "../../include/stlpose_hip.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -14,12 +15,18 @@ struct alignas(16) V16 {
 };
 
 int stl_set_error(const char* fmt, ...);
+// Name of the kernel instantiation the calling thread launched last (stl_last_kernel(): bench.py groups its per-launch
+// timings by it, so the roofline entry names what rocprofv3's kernel trace names).  Templated launchers note their
+// instantiation ("conv_core_kernel<bf16,3,4,2,4,2,3,1,0,1,-1,0>": the template arguments in declaration order); every
+// other launch site is named by its STL_LAUNCH_CHECK string.
+void stl_note_kernel(const char* name, bool specific);
 #define STL_CHECK(cond, ...)                 \
     do {                                     \
         if (!(cond)) return stl_set_error(__VA_ARGS__); \
     } while (0)
 #define STL_LAUNCH_CHECK(name)                                                       \
     do {                                                                             \
+        stl_note_kernel(name, false);                                                \
         hipError_t e_ = hipGetLastError();                                           \
         if (e_ != hipSuccess) return stl_set_error("%s: %s", name, hipGetErrorString(e_)); \
     } while (0)
@@ -259,3 +266,12 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// "base<bf16,a0,a1,...>" for stl_note_kernel (built once per instantiation: function-local static in the launcher)
+template <typename T>
+static inline const char* stl_kname(char (&buf)[160], const char* base, std::initializer_list<int> args) {
+    int n = snprintf(buf, sizeof(buf), "%s<%s", base, sizeof(T) == 2 ? "bf16" : "f32");
+    for (int a : args) n += snprintf(buf + n, sizeof(buf) - n, ",%d", a);
+    snprintf(buf + n, sizeof(buf) - n, ">");
+    return buf;
+}

@@ -12,28 +12,16 @@ struct Program {
     hipEvent_t fork = nullptr;
     std::vector<hipEvent_t> join;
     int nstreams = 1;
-    // STL_SYNC_VALUES=1 (experiment): cross-stream dependencies as stream memory operations on 8-byte signal-memory words
-    // (hipStreamWriteValue32 behind the producer, hipStreamWaitValue32 >= run counter in front of the consumer) instead of events
-    std::vector<void*> flag;     // per recording op
-    uint32_t gen = 0;
-    bool values = false;
 };
 }  // namespace
 
 // Flags of the program's cross-stream events.  A default HIP event performs a SYSTEM-scope fence (cache write-back and
 // invalidation, "and the performance impact of those actions on the execution of following work", hip_runtime_api.h) when it is
 // recorded; producers and consumers of a program's events are kernels on the SAME device, for which device scope orders the data
-// (the host reads results only behind a stream / device synchronisation, which fences on its own; RCCL's kernels that pick up a
-// gradient bucket run on this device too).  STL_EVENT_FLAGS: 1 (default) = hipEventDisableTiming | hipEventDisableSystemFence,
-// 0 = hipEventDisableTiming only, 2 = + hipEventReleaseToDevice.  One call, two rounds: 14.69-14.71 / 14.52-14.57 / 14.66-14.71 ms
-// per step for 0 / 1 / 2; the whole GPU suite (bit-exact argmax at B = 32, two-rank trainer) passes with 1.
-static unsigned event_flags() {
-    static const int mode = getenv("STL_EVENT_FLAGS") ? atoi(getenv("STL_EVENT_FLAGS")) : 1;
-    unsigned f = hipEventDisableTiming;
-    if (mode == 1) f |= hipEventDisableSystemFence;
-    if (mode == 2) f |= hipEventReleaseToDevice;
-    return f;
-}
+// (the host reads results only behind a stream / device synchronisation, which fences on its own).  Round 3, one call, two rounds:
+// 14.69-14.71 ms per step with the default flags, 14.52-14.57 with hipEventDisableSystemFence, 14.66-14.71 with
+// hipEventReleaseToDevice; stream memory operations (hipStreamWriteValue32 / WaitValue32) instead of events: 15.45 (removed).
+static unsigned event_flags() { return hipEventDisableTiming | hipEventDisableSystemFence; }
 
 extern "C" int stl_program_create(const stl_op* ops, int n, int nstreams, void** out) {
     STL_CHECK(ops && out && n >= 0 && nstreams >= 1 && nstreams <= 16, "program_create: bad arguments");
@@ -64,22 +52,6 @@ extern "C" int stl_program_create(const stl_op* ops, int n, int nstreams, void**
             p->ev.push_back(e);
         }
     }
-    if (getenv("STL_SYNC_VALUES") && atoi(getenv("STL_SYNC_VALUES")) == 1) {
-        int can = 0, dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev);
-        if (can) {
-            p->values = true;
-            for (size_t i = 0; i < p->ev.size(); ++i) {
-                void* w = nullptr;
-                if (hipExtMallocWithFlags(&w, 8, hipMallocSignalMemory) != hipSuccess || hipMemset(w, 0, 8) != hipSuccess) {
-                    p->values = false;
-                    break;
-                }
-                p->flag.push_back(w);
-            }
-        }
-    }
     (void)hipEventCreateWithFlags(&p->fork, event_flags());
     p->join.resize(nstreams);
     for (int s = 0; s < nstreams; ++s) (void)hipEventCreateWithFlags(&p->join[s], event_flags());
@@ -92,7 +64,6 @@ extern "C" int stl_program_destroy(void* h) {
     if (!p) return 0;
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->join) (void)hipEventDestroy(e);
-    for (void* w : p->flag) (void)hipFree(w);
     if (p->fork) (void)hipEventDestroy(p->fork);
     delete p;
     return 0;
@@ -115,17 +86,11 @@ extern "C" int stl_program_run(void* h, void* const* streams) {
             STL_CHECK(hipStreamWaitEvent((hipStream_t)streams[s], p->fork, 0) == hipSuccess, "program_run: fork wait failed");
     }
     const int n = (int)p->ops.size();
-    if (p->values) ++p->gen;
     for (int i = 0; i < n; ++i) {
         const stl_op& o = p->ops[i];
         void* st = streams[o.stream];
-        for (int w = 0; w < o.nwait; ++w) {
-            if (p->values)
-                STL_CHECK(hipStreamWaitValue32((hipStream_t)st, p->flag[p->ev_of[o.wait[w]]], p->gen, hipStreamWaitValueGte, 0xFFFFFFFFu) == hipSuccess,
-                          "program_run: value wait failed");
-            else
-                STL_CHECK(hipStreamWaitEvent((hipStream_t)st, p->ev[p->ev_of[o.wait[w]]], 0) == hipSuccess, "program_run: wait failed");
-        }
+        for (int w = 0; w < o.nwait; ++w)
+            STL_CHECK(hipStreamWaitEvent((hipStream_t)st, p->ev[p->ev_of[o.wait[w]]], 0) == hipSuccess, "program_run: wait failed");
         int rc;
         switch (o.kind) {
             case STL_OP_CONV: rc = stl_conv_forward(static_cast<const stl_conv*>(o.desc), st); break;
@@ -169,15 +134,7 @@ extern "C" int stl_program_run(void* h, void* const* streams) {
             default: return stl_set_error("program_run: op %d has unknown kind %d", i, o.kind);
         }
         if (rc != 0) return rc;
-        if (o.record) {
-            if (p->values) {
-                STL_CHECK(hipStreamWriteValue32((hipStream_t)st, p->flag[p->ev_of[i]], p->gen, 0) == hipSuccess, "program_run: value write failed");
-                if (o.kind == STL_OP_BN_GRADS_RANGE)   // gradient-bucket ends are also picked up from outside (stl_program_wait_op)
-                    STL_CHECK(hipEventRecord(p->ev[p->ev_of[i]], (hipStream_t)st) == hipSuccess, "program_run: record failed");
-            } else {
-                STL_CHECK(hipEventRecord(p->ev[p->ev_of[i]], (hipStream_t)st) == hipSuccess, "program_run: record failed");
-            }
-        }
+        if (o.record) STL_CHECK(hipEventRecord(p->ev[p->ev_of[i]], (hipStream_t)st) == hipSuccess, "program_run: record failed");
     }
     for (int s = 1; s < p->nstreams; ++s) {
         STL_CHECK(hipEventRecord(p->join[s], (hipStream_t)streams[s]) == hipSuccess, "program_run: join record failed");

@@ -11,6 +11,30 @@
 #include <type_traits>
 #include "common.cuh"
 
+// Compiled twice by stlpose_amd/build.py (-DSTL_DT=1: bf16 kernels + the C ABI entry points, -DSTL_DT=0: fp32 kernels) so that
+// the two halves build in parallel; STL_DT=2 (default) = one unit.
+#ifndef STL_DT
+#define STL_DT 2
+#endif
+
+constexpr int WG_MAXG = STL_WGRAD_GROUP_MAX;
+struct WgK {
+    stl_wgrad p;           // problem 0 (geometry, tile, nsplit: shared by every member of a group)
+    stl_wgrad_io io[WG_MAXG];   // per member: sources and slab pointer (io[0] mirrors p)
+    int ng;                // members of this launch (1 = plain launch); grid.x = ng * p.nsplit
+    int dbg;
+    int tiles_c, npt, HR, HC, HP, PI, pad, taps;
+    int psg, psh;  // LDS bytes per pixel (32 channels + 16 B pad)
+    int off_cg, off_ch, off_g, off_h;
+    float r_TW, r_HC, r_tc, r_vp, r_PI;  // reciprocals for fdiv
+    unsigned long long m_tc, m_vp, m_PI;  // ceil(2^32 / d): exact n / d = (n * m) >> 32 on the scalar unit for n * d < 2^32
+    int xmap, units, gy, gz;   // XCD-aware block order (see wg_block): units = ng * nsplit pixel ranges, gy x gz channel chunks
+};
+
+// dtype back ends (defined where their kernels are instantiated); wide = the 64 x 64-channel variant (bf16 only)
+int stl_wgrad_backend_bf16(bool wide, const WgK& k, dim3 grid, size_t lds, hipStream_t st);
+int stl_wgrad_backend_f32(bool wide, const WgK& k, dim3 grid, size_t lds, hipStream_t st);
+
 namespace {
 
 #include "conv_common.inc"
@@ -37,19 +61,6 @@ __device__ __forceinline__ int mad24_vsv(int a, int b_uniform, int c) {
 // vector instructions, and everything computed from their result would be vector arithmetic too)
 __device__ __forceinline__ int sdiv(int n, unsigned long long m) { return (int)(((unsigned long long)(uint32_t)n * m) >> 32); }
 
-constexpr int WG_MAXG = STL_WGRAD_GROUP_MAX;
-struct WgK {
-    stl_wgrad p;           // problem 0 (geometry, tile, nsplit: shared by every member of a group)
-    stl_wgrad_io io[WG_MAXG];   // per member: sources and slab pointer (io[0] mirrors p)
-    int ng;                // members of this launch (1 = plain launch); grid.x = ng * p.nsplit
-    int dbg;
-    int tiles_c, npt, HR, HC, HP, PI, pad, taps;
-    int psg, psh;  // LDS bytes per pixel (32 channels + 16 B pad)
-    int off_cg, off_ch, off_g, off_h;
-    float r_TW, r_HC, r_tc, r_vp, r_PI;  // reciprocals for fdiv
-    unsigned long long m_tc, m_vp, m_PI;  // ceil(2^32 / d): exact n / d = (n * m) >> 32 on the scalar unit for n * d < 2^32
-    int xmap, units, gy, gz;   // XCD-aware block order (see wg_block): units = ng * nsplit pixel ranges, gy x gz channel chunks
-};
 
 // Which (member, split, co chunk, ci chunk) a block works on.  Plain order: grid (ng * nsplit, gy, gz).  XCD-aware order
 // (k.xmap, 1-D grid): workgroups go to the eight XCDs round-robin by linear id, so the gy * gz chunk blocks of ONE pixel
@@ -408,275 +419,6 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// Wave-specialised variant (round 3): 8 waves, waves 4-7 LOAD (global -> registers -> BatchNorm(+ReLU) / BatchNorm-backward
-// transform -> LDS), waves 0-3 MULTIPLY (one 16 x 16 quadrant of the block's 32 x 32 channels each, ALL taps), through a
-// double-buffered LDS image with ONE barrier per tile: while the compute waves read tile i out of buffer i & 1 the
-// loaders transform and write tile i + 1 into the other buffer.  In the uniform kernel above the same eight waves do
-// staging, LDS write, fragment reads and MFMAs phase by phase between two barriers (a tile takes 1.67 us of a CU whatever
-// the occupancy, although no single pipe needs more than half of that); here each SIMD hosts one loader and one compute
-// wave, so the vector / LDS-write work of tile i + 1 runs beside the matrix / LDS-read work of tile i.
-// Loader threads keep TWO register sets of loads in flight (tiles i + 1 and i + 2).
-#ifndef WS_WPE
-#define WS_WPE 2   // waves per SIMD of the register budget: 2 = one block per CU (134 VGPRs; 4 = two blocks, 128 VGPRs, spills in the tile loop: 76 vs 41 us)
-#endif
-template <typename T, int KS, int NVH, bool GQ>
-__global__ __launch_bounds__(512, WS_WPE) void wgrad_ws_kernel(const WgK k) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KV = ET<T>::KV, TAPS = KS * KS, TPX = 128;
-    constexpr int KSTEP = 4 * KV;
-    constexpr int NR = sizeof(T) == 2 ? 2 : 4;
-    constexpr int VPX = 32 / KV;
-    constexpr int NL = 256;                       // loader threads
-    constexpr int NVG = TPX * VPX / NL;           // g staging vectors per loader thread (2 bf16 / 4 fp32)
-    constexpr int PS = 32 * (int)sizeof(T) + 16;
-    constexpr int NKT = TPX / KSTEP;
-    const stl_wgrad& p = k.p;
-    const WgBlock wb = wg_block(k);   // (its divisions run on the vector unit and come back as scalars: otherwise every tile term
-    if (!wb.live) return;             // below stays vector arithmetic)
-    const int member = wb.member, bsplit = wb.bsplit;
-    const stl_wgrad_io& io = k.io[member];
-    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wave >= 4;
-    const int co0 = wb.cy * 32, ci0 = wb.cz * 32;
-    float* cgc = reinterpret_cast<float*>(smem + k.off_cg);  // [3][32]
-    float* chc = reinterpret_cast<float*>(smem + k.off_ch);  // [2][32]
-    const int bufsz = k.off_h - k.off_g + k.HP * PS;          // one LDS image: g tile + h halo tile
-    const int tilepx = p.TH * p.TW;
-    const int vpitch = p.Ho + 1;
-    const int hrow = k.HC * PS;
-    const int step = p.nsplit;
-    const int ntile = bsplit < k.npt ? (k.npt - bsplit + step - 1) / step : 0;   // tiles of this block (block-uniform)
-
-    if (loader) {
-        const int ltid = tid - NL;
-        // ---- constants (wave 7: lanes 0-31 those of g, 32-63 those of h), loads issued ahead of the first tiles' loads
-        SrcRaw raw;
-        const bool cw = wave == 7, cg = lane < 32;
-        const int cch = lane & 31;
-        const bool cok = cw && (cg ? co0 + cch < p.Co : ci0 + cch < p.Ci);
-        if (cok) {
-            if (cg) src_raw_load(io.g, co0 + cch, p.Co, raw);
-            else src_raw_load(io.h, ci0 + cch, p.Ci, raw);
-        }
-        // ---- loop-invariant staging descriptors.  Everything a slot needs per tile is straight-line arithmetic on
-        // these (no divergent branches: with one loader wave per SIMD nothing hides a branch bubble or an LDS wait).
-        int g_ty[NVG], g_tx[NVG];
-        const int g_part = ltid % VPX;
-        const bool g_chok = (co0 + g_part * KV) < p.Co, h_chok = (ci0 + g_part * KV) < p.Ci;
-        uint32_t slot_ok = 0;   // bit i: g slot i lies in the tile; bit NVG + i: h slot i lies in the halo tile
-#pragma unroll
-        for (int i = 0; i < NVG; ++i) {
-            const int m = (ltid + i * NL) / VPX;
-            const int ty = fdiv(m, k.r_TW);
-            g_ty[i] = ty, g_tx[i] = m - ty * p.TW;
-            if (m < tilepx && g_chok) slot_ok |= 1u << i;
-        }
-        int h_r[NVH], h_c[NVH];
-        uint32_t h_inside = 0;
-#pragma unroll
-        for (int i = 0; i < NVH; ++i) {
-            const int hp = (ltid + i * NL) / VPX, hr = fdiv(hp, k.r_HC);
-            h_r[i] = hr, h_c[i] = hp - hr * k.HC;
-            if (hp < k.HP && h_chok) slot_ok |= 1u << (NVG + i);
-            if (hp < k.HP) h_inside |= 1u << (NVG + i);   // LDS rows to write (zeros when the channel chunk is beyond Ci)
-        }
-        V16 rgv[2][NVG], rgq[2][GQ ? NVG : 1], rhv[2][NVH];
-        uint32_t okm[2] = {0u, 0u};
-        // Byte offset of a slot = (tile term, scalar unit) + (slot term, computed once) - wraps * (row-pitch term): the only
-        // per-slot multiplies left are 24-bit ones (v_mul_lo_u32 / v_mad_u64_u32 are quarter rate, and with one loader wave
-        // per SIMD the address arithmetic was a third of a tile's time).  32-bit offsets beside a scalar base: the host
-        // routes tensors beyond 4 GB, or with row terms beyond 2^23, to the uniform kernel.
-        const int g_cbytes = p.Co * (int)sizeof(T), h_cbytes = p.Ci * (int)sizeof(T);
-        const int g_wrap = -p.Wo * g_cbytes;                       // one image boundary crossed: real row index one less
-        const int h_wrap = (p.Hi - k.PI) * p.Wi * h_cbytes;
-        const int n_vp = -vpitch, n_PI = -k.PI;
-        uint32_t g_lo[NVG], h_lo[NVH];
-#pragma unroll
-        for (int i = 0; i < NVG; ++i) g_lo[i] = (uint32_t)((g_ty[i] * p.Wo + g_tx[i]) * g_cbytes + (co0 + g_part * KV) * (int)sizeof(T));
-#pragma unroll
-        for (int i = 0; i < NVH; ++i) h_lo[i] = (uint32_t)((h_r[i] * p.Wi + h_c[i]) * h_cbytes + (ci0 + g_part * KV) * (int)sizeof(T));
-        auto fetch = [&](auto SET, int t) __attribute__((always_inline)) {
-            constexpr int S = decltype(SET)::value;
-            // tile terms on the scalar unit
-            const int tr = sdiv(t, k.m_tc), tc = t - tr * k.tiles_c;
-            const int vr0 = tr * p.TH, c0 = tc * p.TW;
-            const int gb0 = sdiv(vr0, k.m_vp), gy0 = vr0 - gb0 * vpitch;
-            const uint32_t g_t = (uint32_t)(((vr0 - gb0) * p.Wo + c0) * g_cbytes);
-            uint32_t ok = 0;
-#pragma unroll
-            for (int i = 0; i < NVG; ++i) {
-                const int oy0 = gy0 + g_ty[i], c = c0 + g_tx[i];
-                const int wr_ = fdiv(oy0, k.r_vp);
-                const int oy = mad24_vsv(wr_, n_vp, oy0);
-                const bool in = ((slot_ok >> i) & 1u) & (gb0 + wr_ < p.B) & (oy < p.Ho) & (c < p.Wo);
-                const uint32_t off = in ? (uint32_t)mad24_vsv(wr_, g_wrap, (int)(g_t + g_lo[i])) : 0u;
-                ok |= in ? 1u << i : 0u;
-                rgv[S][i] = ldg16((const char*)io.g.x + off);
-                if (GQ) rgq[S][i] = ldg16((const char*)io.g.y + off);
-            }
-            const int vrs = vr0 * p.stride, cb = c0 * p.stride - k.pad;
-            const int hb0 = sdiv(vrs, k.m_PI), hy0 = vrs - hb0 * k.PI - k.pad;
-            const uint32_t h_t = (uint32_t)(((hb0 * p.Hi + hy0) * p.Wi + cb) * h_cbytes);
-#pragma unroll
-            for (int i = 0; i < NVH; ++i) {
-                const int iy0 = hy0 + h_r[i], ix = cb + h_c[i];
-                const int wr_ = fdiv(iy0 < 0 ? 0 : iy0, k.r_PI);
-                const int iy = mad24_vsv(wr_, n_PI, iy0);
-                const bool in = ((slot_ok >> (NVG + i)) & 1u) & (iy0 >= 0) & (ix >= 0) & (ix < p.Wi) & (hb0 + wr_ < p.B) & (iy < p.Hi);
-                const uint32_t off = in ? (uint32_t)mad24_vsv(wr_, h_wrap, (int)(h_t + h_lo[i])) : 0u;
-                ok |= in ? 1u << (NVG + i) : 0u;
-                rhv[S][i] = ldg16((const char*)io.h.x + off);
-            }
-            okm[S] = ok;
-        };
-        const float relu_lo = io.h.relu ? 0.f : -INFINITY;
-        // this thread's channel constants live in registers for the whole launch (its channel chunk never changes)
-        float cgr[3][KV], chr_[2][KV];
-        auto write_lds = [&](auto SET, int buf) __attribute__((always_inline)) {
-            constexpr int S = decltype(SET)::value;
-            char* sG = smem + k.off_g + buf * bufsz;
-            char* sH = smem + k.off_h + buf * bufsz;
-#pragma unroll
-            for (int i = 0; i < NVG; ++i) {
-                V16 val = rgv[S][i];
-                if (GQ) val = xform_bnbwd<T>(val, rgq[S][i], cgr[0], cgr[1], cgr[2]);
-                mask16(val, (okm[S] >> i) & 1u);
-                const int v = ltid + i * NL;
-                *reinterpret_cast<V16*>(sG + (v / VPX) * PS + g_part * 16) = val;
-            }
-#pragma unroll
-            for (int i = 0; i < NVH; ++i) {
-                V16 val = rhv[S][i];
-                if (io.h.mode == STL_SRC_BN) val = xform_bn<T>(val, chr_[0], chr_[1], relu_lo);
-                mask16(val, (okm[S] >> (NVG + i)) & 1u);
-                const int v = ltid + i * NL;
-                if ((h_inside >> (NVG + i)) & 1u) *reinterpret_cast<V16*>(sH + (v / VPX) * PS + g_part * 16) = val;
-            }
-        };
-        constexpr std::integral_constant<int, 0> I0{};
-        constexpr std::integral_constant<int, 1> I1{};
-        int t = bsplit;
-        if (ntile > 0) fetch(I0, t);
-        if (ntile > 1) fetch(I1, t + step);
-        if (cw) {
-            float a = 0.f, b = 0.f, cc = 0.f;
-            if (cok) {
-                if (cg) src_raw_finish(io.g, raw, a, b, cc);
-                else src_raw_finish(io.h, raw, a, b, cc);
-            }
-            if (cg) cgc[cch] = a, cgc[32 + cch] = b, cgc[64 + cch] = cc;
-            else chc[cch] = a, chc[32 + cch] = b;
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the constants are in LDS
-        asm volatile("s_barrier" ::: "memory");   // (A) constants visible to the four loader waves (the compute waves take part in the barrier)
-#pragma unroll
-        for (int e = 0; e < KV; ++e) {
-            cgr[0][e] = cgc[g_part * KV + e], cgr[1][e] = cgc[32 + g_part * KV + e], cgr[2][e] = cgc[64 + g_part * KV + e];
-            chr_[0][e] = chc[g_part * KV + e], chr_[1][e] = chc[32 + g_part * KV + e];
-        }
-        // tile i -> buffer i & 1; one barrier after every write (the compute waves wait at the same barrier before reading)
-        int i = 0;
-        while (i < ntile) {
-#ifndef STL_WS_PROBE
-#define STL_WS_PROBE 0   // timing probes (wrong numerics): 1 = no MFMA loop, 2 = no global loads after the prologue, 3 = no LDS writes
-#endif
-            if (STL_WS_PROBE != 3) write_lds(I0, i & 1);
-            if (STL_WS_PROBE != 2 && i + 2 < ntile) fetch(I0, t + 2 * step);
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            asm volatile("s_barrier" ::: "memory");
-            ++i, t += step;
-            if (i >= ntile) break;
-            if (STL_WS_PROBE != 3) write_lds(I1, i & 1);
-            if (STL_WS_PROBE != 2 && i + 2 < ntile) fetch(I1, t + 2 * step);
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            asm volatile("s_barrier" ::: "memory");
-            ++i, t += step;
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------- compute waves
-    const int mt = wave >> 1, nt = wave & 1;
-    const uint32_t lterm = sizeof(T) == 2 ? (lane & 3) * 8 : (lane & 15) * 4;
-    uint32_t gaw[NR], hbw[NKT][NR];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int c = sizeof(T) == 2 ? 8 * g + 4 * i + ((lane & 15) >> 2) : 4 * g + i;
-        gaw[i] = (uint32_t)(uintptr_t)(smem + k.off_g) + c * PS + lterm + mt * 16 * (int)sizeof(T);
-#pragma unroll
-        for (int s_ = 0; s_ < NKT; ++s_) {
-            int m = s_ * KSTEP + c;
-            if (m >= tilepx) m = 0;
-            const int ty = fdiv(m, k.r_TW), tx = m - ty * p.TW;
-            hbw[s_][i] = (uint32_t)(uintptr_t)(smem + k.off_h) + ((ty * p.stride) * k.HC + tx * p.stride) * PS + lterm + nt * 16 * (int)sizeof(T);
-        }
-    }
-    f32x4 acc[TAPS];
-#pragma unroll
-    for (int tp = 0; tp < TAPS; ++tp) acc[tp] = f32x4{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_barrier" ::: "memory");   // (A)
-    for (int i = 0; i < ntile; ++i) {
-        asm volatile("s_barrier" ::: "memory");   // tile i is in buffer i & 1
-        const uint32_t boff = (uint32_t)((i & 1) * bufsz);
-        constexpr int NJ = NKT * TAPS, PF = TAPS >= 4 ? 6 : 2;
-        uint32_t ga[NR], hb[NKT][NR];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            ga[r] = gaw[r] + boff;
-            asm volatile("" : "+v"(ga[r]));
-#pragma unroll
-            for (int s_ = 0; s_ < NKT; ++s_) {
-                hb[s_][r] = hbw[s_][r] + boff;
-                asm volatile("" : "+v"(hb[s_][r]));
-            }
-        }
-        V16 aq[2], bq[PF];
-        auto bfrag = [&](int j) __attribute__((always_inline)) {
-            const int s_ = j / TAPS, tap = j % TAPS;
-            uint32_t ad[NR];
-#pragma unroll
-            for (int r = 0; r < NR; ++r) ad[r] = hb[s_][r] + (tap / KS) * hrow;
-            return frag_at<T>(ad, (tap % KS) * PS);
-        };
-        aq[0] = frag_at<T>(ga, 0);
-#pragma unroll
-        for (int j = 0; j < PF - 1 && j < NJ; ++j) bq[j] = bfrag(j);
-#pragma unroll
-        for (int j = 0; j < (STL_WS_PROBE == 1 ? 1 : NJ); ++j) {
-            const int s_ = j / TAPS, jt = j % TAPS;
-            if (jt == 0 && s_ + 1 < NKT) aq[(s_ + 1) & 1] = frag_at<T>(ga, (s_ + 1) * KSTEP * PS);
-            if (j + PF - 1 < NJ) bq[(j + PF - 1) % PF] = bfrag(j + PF - 1);
-            mma16<T>(acc[jt], aq[s_ & 1], bq[j % PF]);
-        }
-    }
-    {   // every compute wave writes its quadrant, all taps, of the block's slab [Co][taps][Ci]
-        float* slab = io.partial + (size_t)bsplit * p.Co * TAPS * p.Ci;
-        const int ci = ci0 + nt * 16 + (lane & 15), co = co0 + mt * 16 + 4 * g;
-        float* dst = slab + (size_t)co * TAPS * p.Ci + ci;
-        if (ci < p.Ci) {
-#pragma unroll
-            for (int jt = 0; jt < TAPS; ++jt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (co + r < p.Co) dst[((size_t)r * TAPS + jt) * p.Ci] = acc[jt][r];
-        }
-    }
-}
-
-template <typename T, int KS, int NVH, bool GQ>
-int launch_ws(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ws_kernel<T, KS, NVH, GQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((wgrad_ws_kernel<T, KS, NVH, GQ>), grid, dim3(512), lds, st, k);
-    STL_LAUNCH_CHECK("conv_wgrad_ws");
-    return 0;
-}
-
 template <typename T, int KS, int NVH, bool GQ, int TPX = 128, int NW = 4>
 int launch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
     constexpr int OCC = (NVH * NW <= 24 && TPX == 128 && sizeof(T) == 2) ? 2 : 1;
@@ -687,6 +429,9 @@ int launch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
         attr_done = true;
     }
     hipLaunchKernelGGL((wgrad_kernel<T, KS, NVH, GQ, TPX, OCC, NW>), grid, dim3(64 * NW), lds, st, k);
+    static char nbuf[160];
+    static const char* nm = stl_kname<T>(nbuf, "wgrad_kernel", {KS, NVH, GQ, TPX, OCC, NW});
+    stl_note_kernel(nm, true);
     STL_LAUNCH_CHECK("conv_wgrad");
     return 0;
 }
@@ -932,23 +677,21 @@ int launch64(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
         attr_done = true;
     }
     hipLaunchKernelGGL((wgrad64_kernel<T, KS, NVH, GQ, TPX>), grid, dim3(256), lds, st, k);
+    static char nbuf[160];
+    static const char* nm = stl_kname<T>(nbuf, "wgrad64_kernel", {KS, NVH, GQ, TPX});
+    stl_note_kernel(nm, true);
     STL_LAUNCH_CHECK("conv_wgrad64");
     return 0;
 }
 
-template <int KS>
-int dispatch64(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
+#if STL_DT != 0
+int dispatch64(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {   // 1x1 layers, 128-pixel tiles
     const int nvh = ceil_div(k.HP * 8, 256);
     const bool gq = k.p.g.mode == STL_SRC_BNBWD;
-    if (k.p.TH * k.p.TW > 128) {  // 256-pixel tiles: 1x1 only (the 3x3 variant would spill)
-        if constexpr (KS == 1) {
-            if (nvh <= 11) return gq ? launch64<__bf16, KS, 11, true, 256>(k, grid, lds, st) : launch64<__bf16, KS, 11, false, 256>(k, grid, lds, st);
-        }
-    } else {
-        if (nvh <= 6) return gq ? launch64<__bf16, KS, 6, true, 128>(k, grid, lds, st) : launch64<__bf16, KS, 6, false, 128>(k, grid, lds, st);
-    }
+    if (k.p.TH * k.p.TW <= 128 && nvh <= 6) return gq ? launch64<__bf16, 1, 6, true, 128>(k, grid, lds, st) : launch64<__bf16, 1, 6, false, 128>(k, grid, lds, st);
     return stl_set_error("wgrad64: halo of %d pixels is too large for a %d-pixel tile", k.HP, k.p.TH * k.p.TW);
 }
+#endif
 
 // launch grid + block-order fields of k (wg_block): XCD-aware order when there is more than one channel chunk
 // (STL_WGRAD_XCD=0: plain 3-D grid)
@@ -962,17 +705,10 @@ dim3 wg_grid(WgK& k, int units, int gy, int gz) {
 
 // channel tile (64 or 32) of the kernel variant stl_conv_wgrad picks for this problem
 int wgrad_chunk(const stl_wgrad& p) {
-    // Default: 1x1 convolutions only ("k1").  There the wide variant halves the re-reads of the 113 MB
-    // layer1 tensors and its slabs are small (21.8 vs 22.0 ms/step); for 3x3 it loses as much again to
-    // the 4x larger split-K slabs (STL_WGRAD_64=all enables it there, STL_WGRAD_64=0 disables it).
-    const char* e = getenv("STL_WGRAD_64");
-    if (e && e[0] == '0') return 32;
-    if ((!e || e[0] == 'k') && p.ks != 1) {
-        // ... except 3x3 layers with very many pixels per weight (layer1.conv2 at 96x72): slabs are small there too
-        const int64_t minpx = getenv("STL_WGRAD_64_MINPX") ? atoll(getenv("STL_WGRAD_64_MINPX")) : (int64_t)1 << 62;
-        if ((int64_t)p.B * p.Ho * p.Wo < minpx) return 32;
-    }
-    return (p.dtype == STL_BF16 && p.stride == 1 && p.Co >= 64 && p.Ci >= 64) ? 64 : 32;
+    // The wide variant serves the 1x1 convolutions only: there it halves the re-reads of the 113 MB layer1 tensors and its
+    // slabs are small (21.8 vs 22.0 ms per step in round 1; without it 15.48 vs 14.5 in round 3).  For 3x3 layers it loses as
+    // much again to the 4x larger split-K slabs and to its 256 VGPRs (15.33 -> 16.42-17.24 ms per step): removed in round 4.
+    return (p.dtype == STL_BF16 && p.ks == 1 && p.stride == 1 && p.Co >= 64 && p.Ci >= 64) ? 64 : 32;
 }
 
 template <typename T, int KS>
@@ -988,36 +724,14 @@ int dispatch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
     const int vpx = 32 / ET<T>::KV;
     const int nvh = ceil_div(k.HP * vpx, 256);
     const bool gq = k.p.g.mode == STL_SRC_BNBWD;
-    if (k.p.TH * k.p.TW > 128) {  // 256-pixel tiles: bf16, halo of at most 6 vectors per thread
-        if constexpr (sizeof(T) == 2) {
-            if (nvh <= 6) return gq ? launch<T, KS, 6, true, 256>(k, grid, lds, st) : launch<T, KS, 6, false, 256>(k, grid, lds, st);
-        }
-        return stl_set_error("wgrad: 256-pixel tiles need bf16 and a halo of at most 384 pixels (have %d)", k.HP);
-    }
-    if constexpr (KS == 3) {   // wave-specialised kernel (STL_WGRAD_WS, opt-in): loaders beside MFMA waves, double-buffered LDS
-        // STL_WGRAD_WS: 1 = every 3x3 layer, 2 = only the layers of the single-branch tail (>= 200000 pixels, Ci >= 64), default 0.
-        // In one call, three rounds each: 14.68-14.71 / 14.54-14.58 / **14.50-14.54** ms per step -- the wave-specialised kernel is
-        // faster alone (41.9 vs 52.1 us for 28 tiles per block) but holds 134 VGPRs x 8 waves and 100 KB of LDS, one block per CU,
-        // and beside the conv kernels of stages 2-4 that costs more than its tiles gain.  Read per call (tests).
-        const int ws_env = getenv("STL_WGRAD_WS") ? atoi(getenv("STL_WGRAD_WS")) : 0;
-        const int nvl = ceil_div(k.HP * vpx, 256);
-        const size_t lds_ws = (size_t)k.off_g + 2 * ((size_t)(k.off_h - k.off_g) + (size_t)k.HP * k.psh);
-        const bool tail_like = (int64_t)k.p.B * k.p.Ho * k.p.Wo >= 200000 && k.p.Ci >= 64;
-        if (ws_env && lds_ws <= 150 * 1024 && (ws_env != 2 || tail_like)) {
-            if (nvl <= 3) return gq ? launch_ws<T, KS, 3, true>(k, grid, lds_ws, st) : launch_ws<T, KS, 3, false>(k, grid, lds_ws, st);
-            if (nvl <= 6) return gq ? launch_ws<T, KS, 6, true>(k, grid, lds_ws, st) : launch_ws<T, KS, 6, false>(k, grid, lds_ws, st);
-            if (nvl <= 9) return gq ? launch_ws<T, KS, 9, true>(k, grid, lds_ws, st) : launch_ws<T, KS, 9, false>(k, grid, lds_ws, st);   // stride 2: 33 x 17 halo
-        }
-    }
+    STL_CHECK(k.p.TH * k.p.TW <= 128, "wgrad: tiles of more than 128 pixels are not supported");
     if constexpr (KS == 3) {   // 8 waves: quadrants x two tap groups, half the staging work per thread (bf16 and fp32)
-        static const int nw_env = getenv("STL_WGRAD_NW") ? atoi(getenv("STL_WGRAD_NW")) : 8;
-        if (nw_env == 8) {
-            const int nvh8 = ceil_div(k.HP * vpx, 512);
-            if (nvh8 <= 2) return gq ? launch<T, KS, 2, true, 128, 8>(k, grid, lds, st) : launch<T, KS, 2, false, 128, 8>(k, grid, lds, st);
-            if (nvh8 <= 3) return gq ? launch<T, KS, 3, true, 128, 8>(k, grid, lds, st) : launch<T, KS, 3, false, 128, 8>(k, grid, lds, st);
-            if (nvh8 <= 5) return gq ? launch<T, KS, 5, true, 128, 8>(k, grid, lds, st) : launch<T, KS, 5, false, 128, 8>(k, grid, lds, st);
-            if (nvh8 <= 9) return gq ? launch<T, KS, 9, true, 128, 8>(k, grid, lds, st) : launch<T, KS, 9, false, 128, 8>(k, grid, lds, st);
-        }
+        const int nvh8 = ceil_div(k.HP * vpx, 512);
+        if (nvh8 <= 2) return gq ? launch<T, KS, 2, true, 128, 8>(k, grid, lds, st) : launch<T, KS, 2, false, 128, 8>(k, grid, lds, st);
+        if (nvh8 <= 3) return gq ? launch<T, KS, 3, true, 128, 8>(k, grid, lds, st) : launch<T, KS, 3, false, 128, 8>(k, grid, lds, st);
+        if (nvh8 <= 5) return gq ? launch<T, KS, 5, true, 128, 8>(k, grid, lds, st) : launch<T, KS, 5, false, 128, 8>(k, grid, lds, st);
+        if (nvh8 <= 9) return gq ? launch<T, KS, 9, true, 128, 8>(k, grid, lds, st) : launch<T, KS, 9, false, 128, 8>(k, grid, lds, st);
+        return stl_set_error("wgrad: halo of %d pixels is too large for the 3x3 kernel; shrink the tile", k.HP);
     }
     if (nvh <= 3) return gq ? launch<T, KS, 3, true>(k, grid, lds, st) : launch<T, KS, 3, false>(k, grid, lds, st);
     if (nvh <= 6) return gq ? launch<T, KS, 6, true>(k, grid, lds, st) : launch<T, KS, 6, false>(k, grid, lds, st);
@@ -1028,6 +742,20 @@ int dispatch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
 
 }  // namespace
 
+#if STL_DT != 0
+int stl_wgrad_backend_bf16(bool wide, const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
+    if (wide) return dispatch64(k, grid, lds, st);
+    return k.p.ks == 3 ? dispatch<__bf16, 3>(k, grid, lds, st) : dispatch<__bf16, 1>(k, grid, lds, st);
+}
+#endif
+#if STL_DT != 1
+int stl_wgrad_backend_f32(bool wide, const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
+    if (wide) return stl_set_error("wgrad: the 64 x 64-channel variant is bf16 only");
+    return k.p.ks == 3 ? dispatch<float, 3>(k, grid, lds, st) : dispatch<float, 1>(k, grid, lds, st);
+}
+#endif
+
+#if STL_DT != 0   // the C ABI entry points live in the bf16 (or the only) unit
 extern "C" int stl_debug_wgrad_stamps(long long* host16) {
     return hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_wstamps), 16 * sizeof(long long)) == hipSuccess ? 0 : stl_set_error("stamps: copy failed");
 }
@@ -1065,7 +793,7 @@ static int wgrad_run(const stl_wgrad* const* ps, int ng, void* stream) {
     STL_CHECK(p.stride == 1 || p.stride == 2, "wgrad: stride must be 1 or 2");
     const int kv = p.dtype == STL_BF16 ? 8 : 4;
     STL_CHECK(p.Ci % kv == 0 && p.Co % kv == 0, "wgrad: Ci=%d / Co=%d must be multiples of %d", p.Ci, p.Co, kv);
-    STL_CHECK(p.TH >= 1 && p.TW >= 1 && p.TH * p.TW <= 256, "wgrad: tile exceeds 256 pixels");
+    STL_CHECK(p.TH >= 1 && p.TW >= 1 && p.TH * p.TW <= 128, "wgrad: tile exceeds 128 pixels");
     STL_CHECK((int64_t)p.B * p.Hi * p.Wi * p.Ci < (1ll << 31) && (int64_t)p.B * p.Ho * p.Wo * p.Co < (1ll << 31),
               "wgrad: tensors of 2^31 or more elements are not supported");
     const int pad = p.ks == 3 ? 1 : 0;
@@ -1099,25 +827,25 @@ static int wgrad_run(const stl_wgrad* const* ps, int ng, void* stream) {
     if (wgrad_chunk(p) == 64) {
         k.psg = k.psh = 160;
         k.off_cg = 0, k.off_ch = 3 * 64 * 4, k.off_g = 2048;  // consts: g [3][64] at 0, h [2][64] at 768
-        k.off_h = k.off_g + (p.TH * p.TW > 128 ? 256 : 128) * k.psg;
+        k.off_h = k.off_g + 128 * k.psg;
         const size_t lds64 = (size_t)k.off_h + (size_t)k.HP * k.psh;
         STL_CHECK(lds64 <= 160 * 1024, "wgrad64: tile needs %zu B of LDS (>160 KiB)", lds64);
         STL_CHECK(p.nsplit <= k.npt || p.nsplit == 1, "wgrad: nsplit %d > tiles %d", p.nsplit, k.npt);
         dim3 grid64 = wg_grid(k, p.nsplit * ng, ceil_div(p.Co, 64), ceil_div(p.Ci, 64));
-        return p.ks == 3 ? dispatch64<3>(k, grid64, lds64, st) : dispatch64<1>(k, grid64, lds64, st);
+        return stl_wgrad_backend_bf16(true, k, grid64, lds64, st);
     }
     const int esz = p.dtype == STL_BF16 ? 2 : 4;
     k.psg = k.psh = 32 * esz + 16;
     k.off_cg = 0;
     k.off_ch = 3 * 32 * 4;
     k.off_g = 1024;  // consts: g [3][32] floats at 0, h [2][32] floats at 384 -> 640 B used
-    int szG = (p.TH * p.TW > 128 ? 256 : 128) * k.psg;
+    int szG = 128 * k.psg;
     int szH = k.HP * k.psh;
     k.off_h = k.off_g + szG;
     size_t lds = (size_t)k.off_h + szH;
     STL_CHECK(lds <= 160 * 1024, "wgrad: tile needs %zu B of LDS (>160 KiB)", lds);
     STL_CHECK(p.nsplit <= k.npt || p.nsplit == 1, "wgrad: nsplit %d > tiles %d", p.nsplit, k.npt);
     dim3 grid = wg_grid(k, p.nsplit * ng, ceil_div(p.Co, 32), ceil_div(p.Ci, 32));
-    if (p.dtype == STL_BF16) return p.ks == 3 ? dispatch<__bf16, 3>(k, grid, lds, st) : dispatch<__bf16, 1>(k, grid, lds, st);
-    return p.ks == 3 ? dispatch<float, 3>(k, grid, lds, st) : dispatch<float, 1>(k, grid, lds, st);
+    return p.dtype == STL_BF16 ? stl_wgrad_backend_bf16(false, k, grid, lds, st) : stl_wgrad_backend_f32(false, k, grid, lds, st);
 }
+#endif   // STL_DT != 0

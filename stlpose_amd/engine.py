@@ -160,19 +160,23 @@ class Engine:
         nstat = sum(int(math.prod(s)) for k, s in store.reg.params if _is_bn_weight(k, store.reg)) * 2 * capi.NSHARD
         self.stats = torch.zeros(max(nstat, 1), dtype=torch.float64, device=self.dev)
         self.rstats = torch.zeros(max(nstat, 1), dtype=torch.float64, device=self.dev) if training else None
-        self.nstreams = int(os.environ.get("STLPOSE_STREAMS", "4"))
-        # weight-gradient streams: "0" = none (same stream as the branch), "1" = one per branch stream,
-        # "n<k>" = k shared streams (branch s -> weight-gradient stream s % k)
-        # "auto": no extra streams -- every off-chain launch (weight gradients, slab reductions) is list-scheduled
-        # onto the branch stream that is free first (_balance_streams)
-        wgs = os.environ.get("STLPOSE_WGRAD_STREAMS", "auto")
-        self.wgrad_auto = wgs == "auto"
-        self.wgrad_streams = wgs not in ("0", "auto")
-        self.nwstreams = 0 if not self.wgrad_streams else (int(wgs[1:]) if wgs.startswith("n") else self.nstreams)
+        # ---- the planner's knobs (all of them; INTEGRATION.md lists what each is for and what was measured)
+        env = os.environ.get
+        self.nstreams = int(env("STLPOSE_STREAMS", "4"))          # HIP streams = hardware queues of the plan (4 compute pipes)
+        # block-end sums z = ReLU(BN(y) + skip) formed by the consuming conv1 (STL_SRC_BNADD) for layers of at least this many
+        # channels.  Bit-identical to the two-launch form and time-neutral on MI355X (round 3, all 69 eligible sums merged:
+        # 15.50 vs 15.33-15.43 ms per step; C <= 32 / C <= 64 / C >= 64 / C >= 128 only: 15.53 / 15.51 / 15.45 / 15.36): the conv
+        # re-forms the sum for every halo pixel and every output-channel block, which costs what the saved launch bought.
+        self.merge_minc = int(env("STLPOSE_MERGE_MINC", "128"))
+        self.bucket_mb = float(env("STLPOSE_BUCKET_MB", "32"))    # gradient bucket size (16 -> 32 MB: 16.79 -> 16.66 ms per step)
+        # block budget of a weight-gradient launch (a group shares it): 512 = two 8-wave blocks per CU, which hide each other's
+        # tile latency (round 3, grouped launches: 128 / 256 / 512 / 768 blocks = 17.65 / 16.03 / 15.36 / 15.57 ms per step)
+        self.wgrad_blocks = int(env("STLPOSE_WGRAD_BLOCKS", "512"))
+        # members per grouped launch (round 3 at 256 blocks: 1 / 2 / 4 / 8 = 15.87 / 15.64 / 16.03 / 17.51; 4 at 512 blocks: 15.36)
+        self.wgrad_group = int(env("STLPOSE_WGRAD_GROUP", "4"))
+        self.skip_wgrad = env("STLPOSE_SKIP_WGRAD", "0") != "0"   # calibration only (wrong numerics): no weight-gradient launches
         self._stream = 0
-        self._fwd_streams = max(1, min(self.nstreams, int(os.environ.get("STLPOSE_FWD_STREAMS", str(self.nstreams)))))   # streams of the FORWARD program only
         self._side = None
-        self._chain_mask = bool(os.environ.get("STLPOSE_CUMASK_CHAIN", ""))
         self._stats_used = 0
         self._wk_elems = 0
         self._wk_fix: List[Tuple] = []
@@ -181,8 +185,6 @@ class Engine:
         self._build_tables()
         if training:
             self._build_backward()
-        if os.environ.get("STLPOSE_ISSUE_ORDER", "0") != "0":
-            self.fwd_ops = self._issue_order(self.fwd_ops)
 
     # ------------------------------------------------------------------ allocation helpers
     def _alloc(self, nbytes: int) -> torch.Tensor:
@@ -231,22 +233,6 @@ class Engine:
     def set_stream(self, s: int):
         self._stream = s % self.nstreams
 
-    # opt-in: measured 18.4 -> 18.8 ms/step -- every chain moved to another stream pays a cross-stream event wait
-    # (~6 us) at both ends, more than the serialisation it removes
-    balance_exchange = os.environ.get("STLPOSE_BALANCE_EXCHANGE", "0") != "0"
-    # block-end sums formed by the consuming conv1 (STL_SRC_BNADD).  Bit-identical to the two-launch form and time-neutral on
-    # MI355X (all 69 eligible sums merged: 15.50 vs 15.33-15.43 ms per step; C <= 32 / C <= 64 / C >= 64 / C >= 128 only:
-    # 15.53 / 15.51 / 15.45 / 15.36): the conv re-forms the sum for every halo pixel and every output-channel block, which
-    # costs what the saved launch and tensor pass bought.  Default: the C >= 128 layers (STLPOSE_MERGE_MINC / _MAXC).
-    merge_block_end = os.environ.get("STLPOSE_MERGE_BLOCK_END", "1") != "0"
-
-    def est_cost(self, x: "Act", cout: int, ks: int, stride: int, hop: int = 0) -> float:
-        """Estimated duration (us) of one conv of an exchange chain (arch._exchange_module): launch + latency chain
-        plus input and output bytes at ~2 TB/s; hop k of a stride-2 chain sees a map 4^k times smaller."""
-        h, w = x.H >> hop, x.W >> hop
-        ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
-        return 12.0 + (x.B * h * w * x.C + x.B * ho * wo * cout) * self.esz / 2.0e6
-
     def stem_input(self) -> Act:
         B, H, W = self.B, self.H, self.W
         Ho, Wo = H // 2, W // 2
@@ -282,11 +268,9 @@ class Engine:
         p.ks, p.stride, p.stuff = kks, kstride, 0
         p.TH, p.TW, p.shape = 0, 0, -1
         capi.call("stl_conv_plan", C.byref(p))  # block shape + pixel tile, searched once
-        p.grid_pct = self._grid_pct(ck)
         reads, writes = [x.ptr], [y.ptr]
         pend = x.pending
-        if (pend is not None and self.merge_block_end and kks == 3 and kstride == 1 and pend[0][2] == self._stream % self._fwd_streams
-                and int(os.environ.get("STLPOSE_MERGE_MINC", "128")) <= x.C <= int(os.environ.get("STLPOSE_MERGE_MAXC", "4096"))
+        if (pend is not None and kks == 3 and kstride == 1 and pend[0][2] == self._stream and self.merge_minc <= x.C
                 and capi.lib().stl_conv_bnadd_ok(C.byref(p)) == 1):
             # Residual block end z = ReLU(BN(y2) + skip) whose FIRST consumer is this 3x3 convolution (the next unit's
             # conv1): the sum is formed while the conv stages its tiles and written out once from the tile interiors
@@ -305,7 +289,7 @@ class Engine:
         if self.training:
             p.out_stats = self.stats.data_ptr() + 8 * bn.stats_off
         self._wk_fix.append((p, "w", ci.fwd_off))
-        self.fwd_ops.append(("stl_conv_forward", p, self._stream % self._fwd_streams, reads, writes))
+        self.fwd_ops.append(("stl_conv_forward", p, self._stream, reads, writes))
         x.consumers += 1
         self.tape.append(("conv", x, y, ci, (kks, kstride), self._stream))
         return y
@@ -326,7 +310,7 @@ class Engine:
             p.t[i].shift = s
             a.consumers += 1
         p.out = z.ptr
-        op = ("stl_fuse_forward", p, self._stream % self._fwd_streams, [a.ptr for a, _, _ in terms], [z.ptr])
+        op = ("stl_fuse_forward", p, self._stream, [a.ptr for a, _, _ in terms], [z.ptr])
         self.fwd_ops.append(op)
         self.tape.append(("fuse", terms, z, relu, self._stream))
         if relu and len(terms) == 2 and all(s == 0 for _, s, _ in terms):
@@ -376,15 +360,6 @@ class Engine:
             return int(key[10])
         return 1 if not key.startswith("final") else self.nstreams
 
-    def _grid_pct(self, key: str) -> int:
-        """STLPOSE_CAP_SCALE='p1,p2,p3,p4': persistent-grid size (per cent of the kernel's default) of a launch that
-        runs beside 0 / 1 / 2 / 3 other branch chains."""
-        spec = os.environ.get("STLPOSE_CAP_SCALE", "")
-        if not spec:
-            return 0
-        pcts = [int(v) for v in spec.split(",")]
-        return pcts[min(self._active_of(key), self.nstreams, len(pcts)) - 1]
-
     # ------------------------------------------------------------------ backward program
     def _new_grad(self, a: Act) -> torch.Tensor:
         return self._act_tensor(a.B, a.H, a.W, a.C)
@@ -397,24 +372,18 @@ class Engine:
         J = self.out.shape[1]
         self.dout = torch.zeros_like(self.out)
         producer = {id(n[2]): n for n in self.tape if n[0] == "fuse"}
-        fuse_block_end = os.environ.get("STLPOSE_FUSE_BLOCK_END", "1") != "0"
-        # opt-in (STLPOSE_FUSED_BWD=1): measured on MI355X the fused launch is 36-38 us against 22 + 25 us for
-        # the two stand-alone launches and moves fewer bytes, but it puts the weight-gradient work on the
-        # data-gradient chain (the critical path) at two blocks per CU: 20.4 vs 19.7 ms per step
-        fused_bwd = os.environ.get("STLPOSE_FUSED_BWD", "0") != "0"
-        fused_c = os.environ.get("STLPOSE_FUSED_C", "32,64").split(",")
         # ---- gradient buckets: contiguous suffixes of the flat gradient buffer, closed as soon as every
         # parameter in them has its slabs / BatchNorm reductions complete (backward finishes the last
         # layers first).  Each bucket gets one ranged slab reduction + BN-gradient launch inside the
         # program, so the step has no serial tail, and an event a data-parallel all-reduce can wait on.
         self.buckets: List[dict] = []
-        bucket_min = int(float(os.environ.get("STLPOSE_BUCKET_MB", "32")) * (1 << 20) / 4)   # 16 -> 32 MB: 16.79 -> 16.66 ms/step (fewer, larger reductions and collectives)
+        bucket_min = int(self.bucket_mb * (1 << 20) / 4)
         bk = dict(done=0, lo=st.nparam, hi=st.nparam, slab0=0, reads=[], strm=0, wuse=[])
         # The serial tail of backward (layer1 + stem: one branch, 113 MB tensors) finishes last.  Close a bucket
         # where it begins, whatever its size, so that the final slab reduction (the only work left after the last
         # weight gradient, in front of the optimiser) covers just the stem / layer1 slabs instead of every layer
         # since the last 16 MB boundary.
-        tail_keys = [k for k in os.environ.get("STLPOSE_BUCKET_TAIL", "transition1.0.0.weight,layer1.1.conv1.weight").split(",") if k]
+        tail_keys = ["transition1.0.0.weight", "layer1.1.conv1.weight"]
         force_at = {st.param_off[k] for k in tail_keys if k in st.param_off}
 
         def bucket_add(off: int, size: int):
@@ -422,31 +391,14 @@ class Engine:
             bk["lo"] = min(bk["lo"], off)
 
         self._wg_pending: Dict[Tuple, List] = {}   # grouped weight gradients waiting for their group to fill
-        # STLPOSE_WGRAD_DEFER=1: a full group is not issued where it fills (in the middle of its branch's data-gradient chain,
-        # on that chain's own stream) but when the reverse walk leaves the branch: the chain reaches the exchange earlier and the
-        # weight gradients run beside the exchange's small launches
-        self._wg_ready: List[Tuple] = []
-        self._wg_defer = os.environ.get("STLPOSE_WGRAD_DEFER", "0") != "0"
-        # how many layers share each weight-gradient shape.  STLPOSE_WGRAD_COUNT=1 sizes a shape's groups by it, so that a shape
-        # which occurs once (transition convs, the stem) gets the whole block budget instead of a quarter -- measured 0.04-0.06 ms
-        # per step SLOWER (15.17 / 15.13 / 15.12 vs 15.11 / 15.09 / 15.07): these launches run beside the data-gradient chain of the
-        # bandwidth-bound tail, and fewer blocks disturb it less.  Off by default.
-        self._wg_count: Dict[Tuple, int] = {}
-        for node in self.tape:
-            if node[0] == "conv":
-                _, x_, y_, _ci, (kk_, ss_), _s = node
-                kkey = (x_.C, y_.C, kk_, ss_, x_.H, x_.W)
-                self._wg_count[kkey] = self._wg_count.get(kkey, 0) + 1
-
         def bucket_close(force: bool = False):
             complete = bk["done"] == bk["hi"] - bk["lo"]          # suffix [lo, hi) fully covered
             force = force or (complete and bk["lo"] in force_at)
             if not complete or bk["done"] == 0 or (bk["done"] < bucket_min and not force):
                 return
             assert complete
-            self._flush_ready_groups(ops)
             for key in list(self._wg_pending):                     # the bucket's slab reduction reads every member's slabs
-                self._flush_wgrad_group(ops, key, now=True)
+                self._flush_wgrad_group(ops, key)
             rr, br = capi.ReduceRange(), capi.BNRange()
             b = dict(lo=bk["lo"], hi=bk["hi"], slab0=bk["slab0"], slab1=len(self.slabs), rr=rr, br=br, wuse=list(bk["wuse"]))
             wstrm = bk["strm"]
@@ -471,7 +423,7 @@ class Engine:
             if kind == "head":
                 _, x, key, joints = node
                 x.bwd_seen += 1
-                nblk = max(1, min(int(os.environ.get("STLPOSE_HEAD_BLOCKS", "256")), math.ceil(x.B * x.H * x.W / 256)))   # <= one 256-pixel chunk per block
+                nblk = max(1, min(256, math.ceil(x.B * x.H * x.W / 256)))   # <= one 256-pixel chunk per block
                 dx = self._new_grad(x)
                 nel = joints * x.C + joints
                 part_off = self._slab_elems
@@ -535,17 +487,8 @@ class Engine:
                 _, x, y, ci, (kks, kstride), strm = node
                 x.bwd_seen += 1
                 assert y.consumers == 1 and y.dt is not None, f"{ci.key}: BN activation must have exactly one consumer"
-                if self._wg_ready and self._wg_ready[0][0][:6] != (x.C, y.C, kks, kstride, x.H, x.W):
-                    self._flush_ready_groups(ops)      # the walk has left the branch whose groups are waiting
                 g = self._gsrc(y)
-                wstrm = (self.nstreams + strm % self.nwstreams) if self.wgrad_streams else strm
-                # Fused backward (conv_core.hip, NCO > 0): the two-conv units' 3x3 stride-1 C -> C convolutions with
-                # C = 32 / 64 -- the bandwidth-bound half of the network -- compute the weight gradient inside the
-                # data-gradient launch: dt and y are fetched once for both, one launch instead of two.
-                fuse_wg = (fused_bwd and kks == 3 and kstride == 1 and x.needs_grad and x.C == y.C and x.C % 32 == 0
-                           and x.C <= 64 and x.H == y.H and x.W == y.W and str(x.C) in fused_c)
-                if not fuse_wg:
-                    self._emit_wgrad(ops, bk, x, y, ci, g, kks, kstride, strm, wstrm)
+                self._emit_wgrad(ops, bk, x, y, ci, g, kks, kstride, strm)
                 bucket_add(ci.master_off, ci.Co * ci.Ci * ci.ks * ci.ks)
                 bucket_add(y.bn.param_off, 2 * y.bn.C)   # gamma, beta of the BatchNorm behind this conv
                 # ---- data gradient
@@ -557,29 +500,10 @@ class Engine:
                 d.Ho, d.Wo, d.Co = x.H, x.W, x.C
                 d.ks, d.stride, d.stuff = kks, 1, int(kstride == 2)
                 d.TH, d.TW, d.shape = 0, 0, -1
-                if fuse_wg:
-                    d.partial = 1   # plan for the fused block shape; the slab pointer is patched in below
                 capi.call("stl_conv_plan", C.byref(d))
-                d.grid_pct = self._grid_pct(ci.key)
                 d.src = g
                 d.w = self.wk.data_ptr() + ci.bwd_off * self.esz
                 dreads = [y.dt.data_ptr()]
-                dwrites = []
-                if fuse_wg:
-                    nslab = x.C // 32
-                    blocks = int(os.environ.get("STLPOSE_FUSED_BLOCKS", "512"))
-                    npt = math.ceil(x.B * (x.H + 1) / d.TH) * math.ceil(x.W / d.TW)
-                    d.wg_nsplit = max(8, min(blocks // nslab, math.ceil(npt / 8) * 8) // 8 * 8)
-                    d.wg_h = self._src(x)
-                    nel = y.C * 9 * x.C
-                    part_off = self._slab_elems
-                    self._slab_elems += (d.wg_nsplit * nel + 3) // 4 * 4
-                    self.slabs.append(dict(part_off=part_off, grad_off=ci.master_off, nsplit=d.wg_nsplit, Co=ci.Co, Ci=ci.Ci,
-                                           ks=ci.ks, Cip=ci.Cik, patch=int(ci.patch), stride=0, struct=d))
-                    dreads.append(x.ptr)
-                    dwrites.append(id(d))
-                    bk["reads"].append(id(d))
-                    bk["strm"] = wstrm
                 if x.kind == "plain":
                     out = self._new_grad(x)
                     if x.grads:
@@ -591,7 +515,7 @@ class Engine:
                     # BatchNorm-backward sums, so no separate pass over dz / z / y is needed.
                     F = producer.get(id(x))
                     same_bn = [a for a, s_, _ in F[1] if a.kind == "bn" and s_ == 0] if F else []
-                    if (fuse_block_end and F is not None and F[3] and len(same_bn) == 1 and not x.grads
+                    if (F is not None and F[3] and len(same_bn) == 1 and not x.grads
                             and x.bwd_seen == x.consumers):
                         ybn = same_bn[0]
                         d.mask_z = x.ptr
@@ -612,7 +536,7 @@ class Engine:
                 d.out = out.data_ptr()
                 # ("wuse", layer): this launch is the last reader of the layer's kernel-layout weights and BatchNorm
                 # parameters in the step -- what an in-program optimiser / weight re-layout of the bucket waits for
-                ops.append(("stl_conv_forward", d, strm, dreads, [out.data_ptr(), ("wuse", ci.master_off)] + dwrites))
+                ops.append(("stl_conv_forward", d, strm, dreads, [out.data_ptr(), ("wuse", ci.master_off)]))
                 bk["wuse"].append(("wuse", ci.master_off))
         bucket_close(force=True)
         for o in ops[n_before:]:
@@ -647,10 +571,7 @@ class Engine:
             i0, i1 = bisect.bisect_left(bn_off, b["lo"]), bisect.bisect_left(bn_off, b["hi"])
             br.rstats, br.grads = self.rstats.data_ptr(), st.grads.data_ptr()
             br.tab, br.n = self._bn_tab.data_ptr() + i0 * C.sizeof(capi.BNRec), i1 - i0
-        ops = self._lag_wgrads(ops, int(os.environ.get("STLPOSE_WGRAD_LAG", "0")))
-        self.bwd_ops = self._balance_streams(ops) if self.wgrad_auto else ops
-        if os.environ.get("STLPOSE_ISSUE_ORDER", "0") != "0":
-            self.bwd_ops = self._issue_order(self.bwd_ops)
+        self.bwd_ops = self._balance_streams(ops)
         for b in self.buckets:   # bucket events are addressed by op index
             b["op"] = next(i for i, o in enumerate(self.bwd_ops) if o[1] is b["br"])
 
@@ -662,8 +583,7 @@ class Engine:
         if name == "stl_conv_forward":
             src = d.B * d.Hi * d.Wi * d.Ci * (2 if d.src.mode == capi.SRC_BNBWD else 1)
             out = d.B * d.Ho * d.Wo * d.Co * (1 + bool(d.mask_y) + bool(d.addend) + bool(d.mask_z))
-            extra = d.B * d.Ho * d.Wo * d.Co if d.partial else 0
-            return 12.0 + (src + out + extra) * esz / 2.0e6 + (10.0 if d.partial else 0.0)
+            return 12.0 + (src + out) * esz / 2.0e6
         if name == "stl_conv_wgrad":
             by = (d.B * d.Hi * d.Wi * d.Ci + d.B * d.Ho * d.Wo * d.Co * (2 if d.g.mode == capi.SRC_BNBWD else 1)) * esz
             return 16.0 + (by + 2.0 * d.nsplit * d.Co * d.Ci * d.ks * d.ks * 4) / 2.0e6
@@ -701,140 +621,62 @@ class Engine:
             if name in ("stl_conv_wgrad", "stl_conv_wgrad_group", "stl_reduce_slabs_range", "stl_bn_grads_range"):
                 active = self._nactive.get(id(desc), self.nstreams)
                 own = strm % self.nstreams
-                if os.environ.get("STLPOSE_BALANCE", "idle") == "idle":
-                    cands = list(range(active, self.nstreams)) + [own]
-                    nq = int(os.environ.get("STLPOSE_OFFCHAIN_QUEUES", "0"))   # 0 = every idle queue
-                    tq = int(os.environ.get("STLPOSE_TAIL_QUEUES", "2"))       # same, for the single-branch tail only (0 = all three); with ungrouped tail launches 1 / 2 / 3: 14.82 / 14.72 / 14.87
-                    if active == 1 and tq:
-                        cands = list(range(1, min(1 + tq, self.nstreams))) + [own]
-                    elif nq:
-                        cands = list(range(active, min(active + nq, self.nstreams))) + [own]
-                else:   # any stream: a foreign weight gradient is issued behind that branch's ops of the module and
-                    cands = range(self.nstreams)   # only waits for a data gradient the next exchange needs anyway
+                cands = list(range(active, self.nstreams)) + [own]
+                if active == 1:   # the single-branch tail: TWO of its three idle queues (see above)
+                    cands = list(range(1, min(3, self.nstreams))) + [own]
                 strm = min(cands, key=lambda s_: (acc[s_], s_ != own))
             acc[strm] += cost
             out.append((name, desc, strm, reads, writes))
         self.sched_estimate_us = list(acc)
         return out
 
-    @staticmethod
-    def _lag_wgrads(ops, lag: int):
-        """Issue every stand-alone weight gradient `lag` launches LATER than the reverse walk emits it.
-        A weight gradient is emitted right behind the data gradient that produces its input, i.e. while
-        that producer is still running; its event wait then parks at the head of a hardware queue that it
-        shares with another branch's data-gradient stream (8 streams -> 4 queues) and blocks that branch.
-        Issued a few launches later the wait is already satisfied when the packet reaches the queue head.
-        A weight gradient never moves past the slab reduction that reads it."""
-        if lag <= 0:
-            return ops
-        out, pending = [], []   # pending: [remaining, op]
-        for op in ops:
-            if op[0] == "stl_conv_wgrad":
-                pending.append([lag, op])
-                continue
-            if op[0] == "stl_reduce_slabs_range":   # its reads include the ids of the bucket's weight gradients
-                need = {r for r in op[3] if not isinstance(r, tuple)}
-                keep = []
-                for item in pending:
-                    if any(w in need for w in item[1][4]):
-                        out.append(item[1])
-                    else:
-                        keep.append(item)
-                pending = keep
-            out.append(op)
-            keep = []
-            for item in pending:
-                item[0] -= 1
-                if item[0] <= 0:
-                    out.append(item[1])
-                else:
-                    keep.append(item)
-            pending = keep
-        out += [item[1] for item in pending]
-        return out
-
-    def _emit_wgrad(self, ops, bk, x: Act, y: Act, ci: ConvInfo, g, kks: int, kstride: int, strm: int, wstrm: int):
-        """Stand-alone weight-gradient launch of one convolution (split-K slabs) on its own stream: weight
-        gradients are off the critical path (only the data-gradient chain is), so they overlap with the chain."""
+    def _emit_wgrad(self, ops, bk, x: Act, y: Act, ci: ConvInfo, g, kks: int, kstride: int, strm: int):
+        """Weight-gradient launch of one convolution (split-K slabs): off the critical path (only the data-gradient chain
+        is on it); _balance_streams places it on an idle queue where there is one."""
         wg = capi.Wgrad()
         wg.dtype = self.dtype
         wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = x.B, x.H, x.W, x.C, y.H, y.W, y.C
         wg.ks, wg.stride = kks, kstride
-        ctile = capi.lib().stl_wgrad_chunk(C.byref(wg))   # 32, or 64 for the wide-channel variant
-        want256 = os.environ.get("STLPOSE_WGRAD_TILE", "128") == "256"
-        if ctile == 64 and kks == 1:
-            want256 = os.environ.get("STLPOSE_WGRAD_K1_TILE", "128") == "256"
-        big = (self.esz == 2 and kstride == 1 and want256
-               and x.B * y.H * y.W >= 256 * 64 and (ctile == 32 or kks == 1))
-        if big:   # 256-pixel tiles: fewer barriers per pixel, but one block per CU
-            wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32, maxpx=256,
-                                       maxhalo=352 if ctile == 64 else 384)
-        else:
-            wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32,
-                                       maxhalo=192 if ctile == 64 else 576)
+        ctile = capi.lib().stl_wgrad_chunk(C.byref(wg))   # 32, or 64 for the wide-channel variant (1x1 layers)
+        wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32, maxhalo=192 if ctile == 64 else 576)
         npt = math.ceil(x.B * (y.H + 1) / wg.TH) * math.ceil(y.W / wg.TW)
         chunks = math.ceil(y.C / ctile) * math.ceil(x.C / ctile)
-        # Block budget per launch: one block per CU.  (End to end, budgets of 128..256 measure the same within
-        # run-to-run noise on MI355X, before and after the kernel was rebuilt: fewer blocks mean fewer slab bytes
-        # but a longer launch; 96 and 384 are clearly worse.)
-        budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS", "512"))   # round 3, grouped launches: 128 / 256 / 512 blocks = 17.65 / 16.03 / 15.36 ms per step (two 8-wave blocks per CU hide each other's tile latency)
-        if ctile == 64:
-            budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS64", "512"))
-        elif kks == 1 and self.esz == 2:
-            budget = int(os.environ.get("STLPOSE_WGRAD_BLOCKS_K1", str(budget)))
+        budget = self.wgrad_blocks
         # The single-branch tail of backward (layer1, stem, transition1) is one serial data-gradient chain beside three idle
         # queues: a group there fills only when the chain has walked through ALL its members (every layer1 group completes
-        # at the first block, i.e. at the very end of the step), so grouped weight gradients pile up behind the chain.
+        # at the first block, i.e. at the very end of the step), so grouped weight gradients pile up behind the chain:
+        # tail launches are not grouped (round 3, groups of 4 / 2 / 1: 15.02 / 14.81 / 14.82 ms per step).
         tail = self._active_of(ci.key) == 1
-        gmax = capi.WGRAD_GROUP_MAX
-        if tail:
-            budget = int(os.environ.get("STLPOSE_TAIL_BLOCKS", str(budget)))
-            gmax = int(os.environ.get("STLPOSE_TAIL_GROUP", "1"))   # 4 / 2 / 1: 15.02 / 14.81 / 14.82 ms per step; with two tail queues 14.73 / 14.72
-        top = max(1, min(npt, budget // chunks if chunks <= budget else 1))
-        wg.nsplit = min(range(1, top + 1), key=lambda ns: (math.ceil(npt / ns) + 0.004 * ns * chunks / 8, ns))
-        wg.h = self._src(x)
-        wg.g = g
+        gsize = 1 if (tail or self.skip_wgrad) else max(1, min(self.wgrad_group, capi.WGRAD_GROUP_MAX, max(1, budget // chunks)))
         # Grouped launches (stl_conv_wgrad_group): weight gradients of one shape -- the 3x3 convolutions of a branch --
         # wait until `gsize` of them are ready and go out as ONE launch that shares the block budget: the four hardware
         # queues carry one off-chain launch instead of gsize (in stages 3 / 4 every queue is busy with a data-gradient
         # chain and each stand-alone weight gradient costs its chain a full launch latency, whatever its size), every
         # block walks gsize times as many pixel tiles, and gsize times fewer split-K slabs are written and reduced.
-        gsize = 1
-        if (ctile == 32 or os.environ.get("STLPOSE_WGRAD_GROUP64", "1") != "0") and not big and os.environ.get("STLPOSE_SKIP_WGRAD", "0") == "0":
-            gsize = max(1, min(int(os.environ.get("STLPOSE_WGRAD_GROUP", "4")), gmax, max(1, budget // chunks),
-                               self._wg_count.get((x.C, y.C, kks, kstride, x.H, x.W), 1) if os.environ.get("STLPOSE_WGRAD_COUNT", "0") != "0" else 99))
-        if gsize > 1:
-            bg = budget // gsize
-            top = max(1, min(npt, bg // chunks if chunks <= bg else 1))
-            wg.nsplit = min(range(1, top + 1), key=lambda ns: (math.ceil(npt / ns) + 0.004 * ns * chunks / 8, ns))
+        bg = budget // gsize
+        top = max(1, min(npt, bg // chunks if chunks <= bg else 1))
+        wg.nsplit = min(range(1, top + 1), key=lambda ns: (math.ceil(npt / ns) + 0.004 * ns * chunks / 8, ns))
+        wg.h = self._src(x)
+        wg.g = g
         nel = y.C * kks * kks * x.C
         part_off = self._slab_elems
         self._slab_elems += (wg.nsplit * nel + 3) // 4 * 4
         self.slabs.append(dict(part_off=part_off, grad_off=ci.master_off, nsplit=wg.nsplit, Co=ci.Co, Ci=ci.Ci,
                                ks=ci.ks, Cip=ci.Cik, patch=int(ci.patch), stride=0, struct=wg))
         bk["reads"].append(id(wg))
-        bk["strm"] = wstrm
-        if os.environ.get("STLPOSE_SKIP_WGRAD", "0") != "0":   # calibration only: no weight-gradient launches, slabs stay zero
+        bk["strm"] = strm
+        if self.skip_wgrad:
             return
         if gsize == 1:
-            ops.append(("stl_conv_wgrad", wg, wstrm, [y.dt.data_ptr(), x.ptr], [id(wg)]))
+            ops.append(("stl_conv_wgrad", wg, strm, [y.dt.data_ptr(), x.ptr], [id(wg)]))
             return
         key = (x.C, y.C, kks, kstride, x.H, x.W, wg.TH, wg.TW, wg.nsplit, int(g.mode), gsize)
         pend = self._wg_pending.setdefault(key, [])
-        pend.append((wg, [y.dt.data_ptr(), x.ptr], wstrm))
+        pend.append((wg, [y.dt.data_ptr(), x.ptr], strm))
         if len(pend) >= gsize:
             self._flush_wgrad_group(ops, key)
 
-    def _flush_ready_groups(self, ops):
-        ready, self._wg_ready = self._wg_ready, []
-        for key, pend in ready:
-            self._wg_pending[key] = pend
-            self._flush_wgrad_group(ops, key, now=True)
-
-    def _flush_wgrad_group(self, ops, key, now: bool = False):
-        if self._wg_defer and not now:
-            self._wg_ready.append((key, self._wg_pending.pop(key)))
-            return
+    def _flush_wgrad_group(self, ops, key):
         pend = self._wg_pending.pop(key, [])
         if not pend:
             return
@@ -868,7 +710,6 @@ class Engine:
         ns = max(o[2] for o in ops) + 1 if ops else 1
         clock = [[-1] * ns for _ in range(ns)]   # clock[s][t]: latest op of stream t known complete at this point of stream s
         snap = {}
-        prune = os.environ.get("STLPOSE_PRUNE_WAITS", "1") != "0"
         for i, (_, _, st_, reads, writes) in enumerate(ops):
             w = set()
             for r in reads:
@@ -880,7 +721,7 @@ class Engine:
                 latest[ops[j][2]] = max(latest.get(ops[j][2], -1), j)
             w = set()
             for t, j in latest.items():
-                if prune and clock[st_][t] >= j:
+                if clock[st_][t] >= j:
                     continue                 # already ordered behind it
                 w.add(j)
                 for u in range(ns):
@@ -893,38 +734,6 @@ class Engine:
                 last[t] = i
         need.update(b["op"] for b in getattr(self, "buckets", []) if ops is self.bwd_ops)
         return waits, need
-
-    def _issue_order(self, ops):
-        """Host issue order = the order in which the launches can START on the device: an in-order replay of the plan's
-        streams with estimated durations (dependencies as in _schedule), launches sorted by their simulated start time.
-        The planner emits a module's branches one after the other (forward: branch 0 first; backward: branch 3 first), so
-        a host that is not far ahead of the device feeds one queue while the others wait for their first launch of the
-        module.  Per-stream order and every read-after-write dependency are preserved (tensors are written once per pass)."""
-        last, sfin, fin, start = {}, {}, [], []
-        for i, op in enumerate(ops):
-            name, desc, st_, reads, writes = op
-            t0 = sfin.get(st_, 0.0)
-            for r in reads:
-                j = last.get(r)
-                if j is not None:
-                    t0 = max(t0, fin[j])
-            d = self._op_cost_us(op) if name != "stl_conv_forward" or True else 0.0
-            start.append(t0)
-            fin.append(t0 + d)
-            sfin[st_] = t0 + d
-            for w in writes:
-                last[w] = i
-        order = sorted(range(len(ops)), key=lambda i: (start[i], i))
-        # safety: a dependency must never be issued after its consumer
-        pos = {i: k for k, i in enumerate(order)}
-        last = {}
-        for i, (_, _, st_, reads, writes) in enumerate(ops):
-            for r in reads:
-                j = last.get(r)
-                assert j is None or pos[j] < pos[i], "issue order breaks a dependency"
-            for w in writes:
-                last[w] = i
-        return [ops[i] for i in order]
 
     def _program(self, ops):
         """Compile an op list into a native program (csrc/program.hip), once."""
@@ -941,17 +750,10 @@ class Engine:
                 for j, wv in enumerate(waits[i]):
                     o.wait[j] = wv
                 o.record = int(i in need)
-            if self._chain_mask:   # every op on a masked stream of its own; streams[0] (the caller's) only forks / joins
-                for i in range(len(ops)):
-                    arr[i].stream += 1
             h = C.c_void_p()
-            capi.call("stl_program_create", arr, len(ops), self.total_streams + (1 if self._chain_mask else 0), C.byref(h))
+            capi.call("stl_program_create", arr, len(ops), self.nstreams, C.byref(h))
             prog = self._progs[key] = (h, arr)
         return prog[0]
-
-    @property
-    def total_streams(self) -> int:
-        return self.nstreams + self.nwstreams
 
     def _run(self, ops, stream: int):
         """Replay a program natively.  With several streams the independent branches of each
@@ -965,51 +767,24 @@ class Engine:
         if rc != 0:
             raise RuntimeError(f"stl_program_run: {self.lib.stl_last_error().decode()}")
 
-    @staticmethod
-    def _cu_range(spec: str):
-        """'lo:hi' -> ctypes uint32[8] with bits lo..hi-1 set (256 CUs), or None for an empty spec."""
-        if not spec:
-            return None
-        lo, hi = (int(v) for v in spec.split(":"))
-        assert 0 <= lo < hi <= 256, f"CU range {spec!r} outside 0..256"
-        words = (C.c_uint32 * 8)()
-        for i in range(lo, hi):
-            words[i >> 5] |= 1 << (i & 31)
-        return words
-
     def _make_streams(self):
-        """HIP streams of the program: index 0 is the caller's stream; 1 .. nstreams-1 the other branch streams;
-        nstreams .. the off-chain (weight-gradient) streams when STLPOSE_WGRAD_STREAMS asks for them.
-        STLPOSE_CUMASK_OFF='lo:hi' restricts the off-chain streams to those compute units, STLPOSE_CUMASK_CHAIN='lo:hi'
-        the branch streams (then ALL ops run on masked streams and the caller's stream only forks / joins)."""
-        off = 1 if self._chain_mask else 0
-        n = self.total_streams + off
+        """HIP streams of the program: index 0 is the caller's stream, 1 .. nstreams-1 the other branch streams.
+        ONE set of side streams per device, shared by every engine (engines never run concurrently): each new HIP stream is
+        another hardware queue, queues are spread round-robin over the four compute pipes, and two ACTIVE queues on one pipe
+        are time-sliced -- a second engine with streams of its own ran its plan at half speed (W32 256x192 as the second
+        plan of a process: 20.8 ms per step instead of 10.2).  (CU-masked streams and HIP stream priorities were measured
+        in round 3 -- 27-92 ms resp. 14.64-14.76 vs 14.66 ms per step -- and removed.)"""
+        n = self.nstreams
         self._stream_arr = (C.c_void_p * n)()
         self._side = []
-        m_off = self._cu_range(os.environ.get("STLPOSE_CUMASK_OFF", ""))
-        m_chain = self._cu_range(os.environ.get("STLPOSE_CUMASK_CHAIN", ""))
-        # ONE set of side streams per device, shared by every engine (engines never run concurrently): each new HIP
-        # stream is another hardware queue, queues are spread round-robin over the four compute pipes, and two ACTIVE
-        # queues on one pipe are time-sliced -- a second engine with streams of its own ran its plan at half speed
-        # (W32 256x192 as the second plan of a process: 20.8 ms per step instead of 10.2).
-        pool = _STREAM_POOL.setdefault((self.dev.index, os.environ.get("STLPOSE_CUMASK_OFF", ""), os.environ.get("STLPOSE_CUMASK_CHAIN", "")), {})
+        pool = _STREAM_POOL.setdefault(self.dev.index, {})
         with torch.cuda.device(self.dev):
             for i in range(1, n):
-                op_stream = i - off                     # index in the planner's numbering
-                mask = m_chain if op_stream < self.nstreams else m_off
-                key = (i, mask is not None)
-                if key not in pool:
-                    if mask is not None:
-                        h = C.c_void_p()
-                        capi.call("stl_stream_create_masked", mask, 8, C.byref(h))
-                        pool[key] = (h, h.value)        # lives as long as the process
-                    else:
-                        # STLPOSE_STREAM_PRIO="p1,p2,p3": HIP priority of side stream 1, 2, 3 (0 normal, -1 high): experiment
-                        pr = [int(v) for v in os.environ.get("STLPOSE_STREAM_PRIO", "").split(",") if v]
-                        s_ = torch.cuda.Stream(device=self.dev, priority=pr[i - 1] if i - 1 < len(pr) else 0)
-                        pool[key] = (s_, s_.cuda_stream)
-                self._side.append(pool[key][0])
-                self._stream_arr[i] = pool[key][1]
+                if i not in pool:
+                    s_ = torch.cuda.Stream(device=self.dev)
+                    pool[i] = (s_, s_.cuda_stream)
+                self._side.append(pool[i][0])
+                self._stream_arr[i] = pool[i][1]
 
     def prep_weights(self, stream: int):
         st = self.store
@@ -1085,17 +860,14 @@ class Engine:
                 self._optim_descs.append(w)
 
         nxt = dict(at)
-        # STLPOSE_OPTIM_STREAM: stream of the optimiser ops; default = the stream of the later bucket's reductions; the last
-        # branch stream is the least loaded queue of the plan (busy 4.4 of 15 ms) and idle in the single-branch tail
-        fixed = os.environ.get("STLPOSE_OPTIM_STREAM", "")
         for idx, op in enumerate(ops):
             new_ops.append(op)
             if idx in nxt:
                 if prev is not None:
-                    emit(prev, int(fixed) if fixed else op[2])
+                    emit(prev, op[2])
                 prev = nxt[idx]
         if prev is not None:
-            emit(prev, int(fixed) if fixed else ops[self.buckets[prev]["op"]][2])
+            emit(prev, ops[self.buckets[prev]["op"]][2])
         self.bwd_ops_opt = new_ops
 
     def bucket_wait(self, i: int, stream: int):
@@ -1104,7 +876,7 @@ class Engine:
         capi.call("stl_program_wait_op", self._program(self.bwd_ops), self.buckets[i]["op"], stream)
 
 
-_STREAM_POOL: Dict[Tuple, Dict] = {}   # (device, mask specs) -> {(stream index, masked): (owner object, hipStream_t)}
+_STREAM_POOL: Dict[int, Dict] = {}   # device index -> {stream index: (owner object, hipStream_t)}
 
 
 def _is_bn_weight(key: str, reg: Registry) -> bool:

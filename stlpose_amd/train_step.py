@@ -64,7 +64,7 @@ class TrainStep:
         self._partial = torch.zeros(self._nblk, dtype=torch.float64, device=dev)
         # HIP-graph capture of a plan that forks onto >2 streams crashes inside hipStreamEndCapture
         # on ROCm 7.2 ("graphs"); such plans are replayed eagerly on their streams.
-        if self.eng.nstreams > 2 or self.eng.wgrad_streams:
+        if self.eng.nstreams > 2:
             use_graph = False
         self.use_graph = use_graph
         self._g_fb: Optional[torch.cuda.CUDAGraph] = None
@@ -137,36 +137,6 @@ class TrainStep:
             capi.call("stl_sgd_step", s.master.data_ptr(), s.grads.data_ptr(), self.m.data_ptr(), s.nparam,
                       self.hyper.data_ptr(), self.step_count.data_ptr(), st)
 
-    def _bucketed_tail(self):
-        """All-reduce, optimiser and next step's weight layouts PER GRADIENT BUCKET, on a side stream
-        that picks each bucket up at its event: the last layers' gradients are reduced, applied and
-        re-laid-out while backward is still working on the early layers, so the step has no serial
-        optimiser / weight-prep section (0.5 ms of 22 before).  The engine is told that the kernel-layout
-        weights are current, so the next forward skips its own weight_prep."""
-        e, s = self.eng, self.store
-        if self._comm is None:
-            self._comm = torch.cuda.Stream(device=self.dev)
-        side = self._comm
-        main = torch.cuda.current_stream(self.dev)
-        side.wait_stream(main)          # ordered after everything already on the main stream (hyper / lr updates)
-        dp = self.dp is not None and (self.world > 1 or self._force_dp)
-        with torch.cuda.stream(side):
-            capi.call("stl_optim_begin_step", self.step_count.data_ptr(), side.cuda_stream)
-            for i, b in enumerate(e.buckets):
-                e.bucket_wait(i, side.cuda_stream)
-                lo, n = b["lo"], b["hi"] - b["lo"]
-                if dp:
-                    self.dp.reduce_bucket(i, force=self._force_dp)   # the side stream (current) waits for the collective
-                if self.kind == ADAM:
-                    capi.call("stl_adam_slice", s.master.data_ptr() + 4 * lo, s.grads.data_ptr() + 4 * lo, self.m.data_ptr() + 4 * lo,
-                              self.v.data_ptr() + 4 * lo, n, self.hyper.data_ptr(), self.step_count.data_ptr(), side.cuda_stream)
-                else:
-                    capi.call("stl_sgd_slice", s.master.data_ptr() + 4 * lo, s.grads.data_ptr() + 4 * lo, self.m.data_ptr() + 4 * lo,
-                              n, self.hyper.data_ptr(), self.step_count.data_ptr(), side.cuda_stream)
-                e.prep_weights_range(i, side.cuda_stream)
-        main.wait_stream(side)
-        self._prepped = True
-
     def _allreduce(self):
         """Bucketed all-reduce overlapped with backward: the backward program is already ENQUEUED when
         this runs; every bucket's collective is issued on a communication stream that waits for the
@@ -206,11 +176,6 @@ class TrainStep:
             self._g_fb.replay()
             self._allreduce()
             self._g_opt.replay()
-        elif os.environ.get("STLPOSE_BUCKET_OPTIM", "0") != "0":
-            # opt-in: measured 21.6 vs 21.5 ms/step on one MI355X -- the overlapped optimiser slices
-            # land in the already saturated tail of backward; kept for multi-GPU experiments
-            self._fwd_bwd()
-            self._bucketed_tail()
         elif self._fused_optim and not self.use_graph:
             self._fwd_bwd(fused_optim=True)
         else:

@@ -70,14 +70,12 @@ def test_sgd_nesterov_step_runs():
     assert np.isfinite(l) and l < l0
 
 
-@pytest.mark.parametrize("bucket_optim", ["0", "1"])
-def test_gradient_buckets_cover_the_flat_buffer_and_dp_path_matches(monkeypatch, bucket_optim):
+def test_gradient_buckets_cover_the_flat_buffer_and_dp_path_matches(monkeypatch):
     """The backward program reduces the weight-gradient slabs bucket by bucket (no serial tail) and
     records an event per bucket; the data-parallel path all-reduces each bucket on a communication
     stream as soon as that event fires.  With ONE rank (RCCL all-reduce = identity) the bucketed path
     must give exactly the gradients and losses of the plain path."""
     import torch.distributed as dist
-    monkeypatch.setenv("STLPOSE_BUCKET_OPTIM", bucket_optim)   # "1": optimiser + weight layouts per bucket as well
     torch.manual_seed(5)
     img, tgt, tw = _batch(4, 256, 192, seed=7)
 
@@ -137,46 +135,10 @@ def test_bf16_gradient_buckets_on_a_one_rank_rccl_group(monkeypatch):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
-def test_fused_backward_matches_separate_launches_at_full_size(monkeypatch, dt):
-    """The opt-in fused backward (STLPOSE_FUSED_BWD=1) against the default stand-alone launches on the benchmarked
-    plan (W32, 384x288, batch 32).  fp32: the data-gradient arithmetic is the same, only the order of the fp32
-    partial sums differs (BatchNorm reductions, split-K slabs) -> every gradient within 1e-3 of its largest
-    element.  bf16: those last-bit differences are re-rounded to bf16 in ~100 consecutive layers, so the bar is
-    the bf16 noise level (direction cosine > 0.999 per tensor, 5 % of the largest element)."""
-    img, tgt, tw = _batch(32, 384, 288, seed=9)
-
-    def grads(fused):
-        monkeypatch.setenv("STLPOSE_FUSED_BWD", fused)
-        torch.manual_seed(21)
-        m = PoseHighResolutionNet("w32", dt).cuda()
-        ts = TrainStep(m, 32, 384, 288, optimizer="sgd", lr=0.0, momentum=0.0)
-        assert sum(1 for o in ts.eng.bwd_ops if o[0] == "stl_conv_forward" and o[1].partial) == (132 if fused == "1" else 0)
-        ts.load_batch(img.cuda(), tgt.cuda(), tw.cuda())
-        l = float(ts.step().item())
-        torch.cuda.synchronize()
-        g = ts.store.grads.clone()
-        st = ts.store
-        del ts, m
-        torch.cuda.empty_cache()
-        return l, g, st
-    l0, g0, st = grads("0")
-    l1, g1, _ = grads("1")
-    assert l0 == l1
-    tol, cosmin = (1e-3, 0.999999) if dt == "fp32" else (5e-2, 0.999)
-    for k, shape in st.reg.params:
-        a = st.param_off[k]
-        n = int(np.prod(shape)) if shape else 1
-        x, y = g0[a:a + n].double(), g1[a:a + n].double()
-        d = float((x - y).abs().max()) / (float(x.abs().max()) + 1e-20)
-        c = float(torch.dot(x, y) / (x.norm() * y.norm() + 1e-30))
-        assert d < tol and c > cosmin, (k, d, c)
-
-
 def test_backward_stream_layouts_give_the_same_gradients(monkeypatch):
-    """The backward planner's stream layouts (off-chain launches list-scheduled onto idle branch streams = default,
-    inline on the branch stream, extra weight-gradient streams, launch lag) only move launches between queues:
-    losses identical, gradients identical up to the order of the fp64 statistics atomics."""
+    """The planner's stream layouts (four streams with the off-chain launches list-scheduled onto idle branch streams =
+    default, two streams, one stream; grouped or single weight gradients) only move launches between queues: losses
+    identical, gradients identical up to the order of the fp64 statistics atomics."""
     img, tgt, tw = _batch(4, 256, 192, seed=13)
 
     def run(env):
@@ -189,15 +151,13 @@ def test_backward_stream_layouts_give_the_same_gradients(monkeypatch):
         l = float(ts.step().item())
         torch.cuda.synchronize()
         g = ts.store.grads.clone()
-        n = ts.eng.total_streams
+        n = ts.eng.nstreams
         for k in env:
             monkeypatch.delenv(k)
         return l, g, n
     l0, g0, n0 = run({})
     assert n0 == 4
-    for env, nstreams in (({"STLPOSE_WGRAD_STREAMS": "0"}, 4), ({"STLPOSE_WGRAD_STREAMS": "1"}, 8),
-                          ({"STLPOSE_WGRAD_STREAMS": "n2", "STLPOSE_WGRAD_LAG": "5"}, 6), ({"STLPOSE_BALANCE": "all"}, 4),
-                          ({"STLPOSE_BALANCE_EXCHANGE": "1"}, 4)):
+    for env, nstreams in (({"STLPOSE_STREAMS": "2"}, 2), ({"STLPOSE_STREAMS": "1"}, 1), ({"STLPOSE_WGRAD_GROUP": "1"}, 4)):
         l1, g1, n1 = run(env)
         assert n1 == nstreams, (env, n1)
         assert l1 == l0, env

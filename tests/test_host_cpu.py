@@ -26,8 +26,15 @@ def test_capi_exports_every_declared_symbol(built_lib):
     from stlpose_amd import capi
     for name in declared:
         assert hasattr(built_lib, name), f"{name} declared in include/stlpose_hip.h but not exported"
-    assert set(capi.SIGNATURES) | {"stl_last_error"} == declared
+    assert set(capi.SIGNATURES) | set(capi.STRING_FUNCS) == declared
     assert built_lib.stl_version() == 1
+
+
+def test_library_was_built_from_this_tree(built_lib):
+    """stl_build_id() = hash of csrc/* and include/* baked in at compile time; it must equal the hash of the sources in
+    the tree, i.e. the .so that travels to the GPU box is the one these sources produce."""
+    from stlpose_amd import build
+    assert built_lib.stl_build_id().decode() == build.source_id()
 
 
 def test_struct_sizes_match_header(built_lib):
@@ -71,7 +78,6 @@ def test_planner_dry_run(monkeypatch):
     """Plan construction needs no GPU: check op counts against SURVEY 8(a) (293 convs incl. head,
     28 upsample terms) and that every BN activation has a single consumer."""
     from collections import Counter
-    monkeypatch.setenv("STLPOSE_FUSED_BWD", "1")
     from stlpose_amd import PoseHighResolutionNet, capi
     from stlpose_amd.engine import Engine
     m = PoseHighResolutionNet("w32", "bf16")
@@ -79,20 +85,12 @@ def test_planner_dry_run(monkeypatch):
     e = Engine(m.arch, m._store, 2, 256, 192, capi.BF16, True)
     f, b = Counter(o[0] for o in e.fwd_ops), Counter(o[0] for o in e.bwd_ops)
     assert f["stl_conv_forward"] + f["stl_head_forward"] == 293
-    # 292 weight gradients: 132 of them (3x3 stride-1 C -> C with C = 32 / 64: 2 x 64 two-conv-unit convs + the 4
-    # bottleneck 3x3s) ride inside their data-gradient launch (fused backward), 160 are stand-alone launches
-    fused = sum(1 for o in e.bwd_ops if o[0] == "stl_conv_forward" and o[1].partial)
-    def nwg(c):   # weight gradients launched stand-alone or as members of grouped launches (round 3)
-        return c["stl_conv_wgrad"] + sum(o[1].n for o in e_.bwd_ops if o[0] == "stl_conv_wgrad_group")
-    e_ = e
-    assert fused == 132 and nwg(b) == 292 - fused
+    # 292 weight gradients, launched stand-alone or as members of grouped launches (round 3)
+    nwg = b["stl_conv_wgrad"] + sum(o[1].n for o in e.bwd_ops if o[0] == "stl_conv_wgrad_group")
     assert b["stl_conv_forward"] == 291 and b["stl_upsample_backward"] == 28
     assert len(e.slabs) == 292 + 2   # + head weight and bias
-    monkeypatch.setenv("STLPOSE_FUSED_BWD", "0")
-    e0 = Engine(m.arch, m._store, 2, 256, 192, capi.BF16, True)
-    e_ = e0
-    c0 = Counter(o[0] for o in e0.bwd_ops)
-    assert nwg(c0) == 292 and 0 < c0["stl_conv_wgrad_group"] < 80 and c0["stl_conv_wgrad"] < 80   # most layers ride in groups of up to 4
+    e0, c0 = e, b
+    assert nwg == 292 and 0 < c0["stl_conv_wgrad_group"] < 80 and c0["stl_conv_wgrad"] < 80   # most layers ride in groups of up to 4
     for o in e0.bwd_ops:
         if o[0] == "stl_conv_wgrad_group":
             ms = o[1].members

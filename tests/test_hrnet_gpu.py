@@ -30,13 +30,8 @@ def _diag(name, lines):
         f.write("\n".join(lines) + "\n")
 
 
-@pytest.mark.parametrize("mode", ["train", "eval", "train-fused"])
+@pytest.mark.parametrize("mode", ["train", "eval"])
 def test_tiny_fp32_vs_reference_golden(golden_dir, mode, monkeypatch):
-    """train-fused: the same golden through the opt-in fused backward launches (data + weight gradient of the
-    3x3 stride-1 C = 32 / 64 convolutions in one kernel)."""
-    if mode == "train-fused":
-        monkeypatch.setenv("STLPOSE_FUSED_BWD", "1")
-        mode = "train"
     g = np.load(os.path.join(golden_dir, f"g1_tiny_{mode}.npz"))
     m = _load_synth(PoseHighResolutionNet("tiny", "fp32")).cuda()
     m.train(mode == "train")

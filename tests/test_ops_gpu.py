@@ -105,32 +105,16 @@ def test_conv_forward_plain_and_stats(case, dt, tile):
     assert torch.allclose(sums[1], (stored * stored).sum(0), rtol=1e-5, atol=1e-3)
 
 
-@pytest.mark.parametrize("wtile", [128, 256, "wide128", "wide256", "ws128"])
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(2, 24, 16, 32, 32, 3, 1), (2, 24, 18, 32, 64, 3, 2), (2, 8, 6, 128, 64, 1, 1),
                                   (4, 48, 36, 64, 64, 3, 1), (4, 24, 18, 128, 128, 3, 1), (2, 24, 18, 64, 256, 1, 1),
                                   (2, 24, 18, 96, 72, 3, 1)])
-def test_conv_bn_relu_chain_forward_backward(case, dt, wtile, monkeypatch):
+def test_conv_bn_relu_chain_forward_backward(case, dt):
     """x --BN(relu) on load--> conv --> y ; backward: BN-backward on load, ReLU mask + r1/r2 in the
     data-gradient epilogue, weight gradient slabs.  Reference: torch autograd through
     batch_norm(train) -> relu -> conv2d -> batch_norm(train)."""
     code, td, tol = DT[dt]
     B, H, W, Ci, Co, ks, s = case
-    if wtile == "ws128":   # opt-in wave-specialised weight gradient (wgrad_ws_kernel: 3x3 only, falls back elsewhere)
-        if ks != 3:
-            pytest.skip("the wave-specialised weight gradient is 3x3 only")
-        monkeypatch.setenv("STL_WGRAD_WS", "1")
-        wtile = 128
-    wide = isinstance(wtile, str)   # opt-in 64x64-channel weight-gradient variant
-    if wide:
-        wtile = int(wtile[4:])
-        if dt != "bf16" or s != 1 or Ci < 64 or Co < 64:
-            pytest.skip("the wide variant is bf16, stride 1, Co and Ci >= 64")
-        monkeypatch.setenv("STL_WGRAD_64", "all")
-    else:
-        monkeypatch.setenv("STL_WGRAD_64", "0")
-    if wtile == 256 and (dt != "bf16" or s != 1):
-        pytest.skip("256-pixel weight-gradient tiles are bf16, stride 1 only")
     g = torch.Generator(device="cuda").manual_seed(2)
     pad = 1 if ks == 3 else 0
     x0 = torch.randn(B, Ci, H, W, device="cuda", generator=g) * 1.5 + 0.3
@@ -180,16 +164,9 @@ def test_conv_bn_relu_chain_forward_backward(case, dt, wtile, monkeypatch):
     wg = capi.Wgrad()
     wg.dtype, wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = code, B, H, W, Ci, Ho, Wo, Co
     wg.ks, wg.stride = ks, s
-    ctile = capi.lib().stl_wgrad_chunk(C.byref(wg))   # 64: wide-channel kernel variant (bf16, Co, Ci >= 64)
-    assert ctile == (64 if wide else 32)
-    if wtile == 256:
-        if ctile == 64 and ks == 3:
-            pytest.skip("the 64x64 3x3 variant has 128-pixel tiles only")
-        wg.TH, wg.TW = choose_tile(B, Ho, Wo, s, ks, x0t.element_size(), bn_cols=32, maxpx=256, maxhalo=352 if ctile == 64 else 384)
-        if wg.TH * wg.TW <= 128:
-            pytest.skip("feature map smaller than one 256-pixel tile")
-    else:
-        wg.TH, wg.TW = choose_tile(B, Ho, Wo, s, ks, x0t.element_size(), bn_cols=32, maxhalo=192 if ctile == 64 else 576)
+    ctile = capi.lib().stl_wgrad_chunk(C.byref(wg))   # 64: wide-channel kernel variant (bf16 1x1 layers with Co, Ci >= 64)
+    assert ctile == (64 if (dt == "bf16" and ks == 1 and Ci >= 64 and Co >= 64) else 32)
+    wg.TH, wg.TW = choose_tile(B, Ho, Wo, s, ks, x0t.element_size(), bn_cols=32, maxhalo=192 if ctile == 64 else 576)
     npt = math.ceil(B * (Ho + 1) / wg.TH) * math.ceil(Wo / wg.TW)
     wg.nsplit = min(3, npt)
     part = torch.full((wg.nsplit * Co * ks * ks * Ci,), float("nan"), device="cuda")
@@ -227,31 +204,6 @@ def test_conv_bn_relu_chain_forward_backward(case, dt, wtile, monkeypatch):
     dx0 = (g1.detach().double() * rstd1) * (dxk - r[0] / n - xhat * r[1] / n)
     ref = x0r.grad.permute(0, 2, 3, 1).reshape(-1, Ci).double()
     assert relerr(dx0, ref) < tol * 3
-    # ---------------- fused backward (one launch: data gradient + weight gradient from the same staged tiles)
-    if ks == 3 and s == 1 and Ci == Co and Ci in (32, 64) and wtile == 128 and not wide:
-        nsp = 16
-        dx2 = torch.full((B * H * W * Ci,), float("nan"), device="cuda", dtype=td)
-        red2 = torch.zeros(capi.NSHARD * 2 * Ci, dtype=torch.float64, device="cuda")
-        part2 = torch.full((nsp * Co * 9 * Ci,), float("nan"), device="cuda")
-        f = capi.Conv()
-        f.shape = -1
-        f.dtype, f.B, f.Hi, f.Wi, f.Ci, f.Ho, f.Wo, f.Co = code, B, Ho, Wo, Co, H, W, Ci
-        f.ks, f.stride, f.stuff = 3, 1, 0
-        f.TH, f.TW = 0, 0
-        f.partial, f.wg_nsplit, f.wg_h = part2.data_ptr(), nsp, p.src
-        capi.call("stl_conv_plan", C.byref(f))
-        assert f.shape == 4
-        f.src, f.w, f.out = gs, wb.data_ptr(), dx2.data_ptr()
-        f.mask_y, f.mask_bn, f.red = x0t.data_ptr(), p.src, red2.data_ptr()
-        capi.call("stl_conv_forward", C.byref(f), stream())
-        torch.cuda.synchronize()
-        assert not torch.isnan(part2).any() and not torch.isnan(dx2.float()).any()
-        assert relerr(dx2.float(), dx.float()) < 1e-6          # same arithmetic as the stand-alone data gradient
-        r2 = red2.view(capi.NSHARD, 2, Ci).sum(0)
-        assert relerr(r2[0], r[0]) < 1e-5 and relerr(r2[1], r[1]) < 1e-5
-        dw2 = part2.view(nsp, Co, 9, Ci).sum(0).view(Co, 3, 3, Ci).permute(0, 3, 1, 2)
-        assert relerr(dw2, wr.grad) < tol * 3
-        assert relerr(dw2, dw) < (1e-5 if dt == "fp32" else 2e-3)   # vs the stand-alone weight gradient (other summation order)
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
@@ -566,7 +518,7 @@ def test_gaussian_targets_match_reference_golden(golden_dir):
         assert np.array_equal(tgt.cpu().numpy() > 0, g[f"{tag}_target"] > 0)
 
 
-@pytest.mark.parametrize("ws", ["0", "1", "0-plain-grid"])
+@pytest.mark.parametrize("ws", ["xcd-grid", "plain-grid"])
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(2, 24, 16, 32, 32, 3, 1, 3), (3, 12, 9, 64, 64, 3, 1, 4), (2, 24, 18, 32, 64, 3, 2, 2), (2, 12, 9, 128, 32, 1, 1, 8)])
 def test_wgrad_group_equals_single_launches(case, dt, ws, monkeypatch):
@@ -574,10 +526,7 @@ def test_wgrad_group_equals_single_launches(case, dt, ws, monkeypatch):
     stl_conv_wgrad launches on the same tensors: every block does the same work in the same order -> bit-identical
     slabs.  Sources: BN (+ReLU) on h and BatchNorm-backward on g, like the layers the planner groups."""
     B, H, W, Ci, Co, ks, s, n = case
-    if ws == "1" and ks != 3:
-        pytest.skip("the wave-specialised weight gradient is 3x3 only")
-    monkeypatch.setenv("STL_WGRAD_WS", ws[0])   # uniform 8-wave kernel (default) / wave-specialised kernel
-    monkeypatch.setenv("STL_WGRAD_XCD", "0" if ws.endswith("plain-grid") else "1")   # XCD-aware block order (default) / plain 3-D grid
+    monkeypatch.setenv("STL_WGRAD_XCD", "0" if ws == "plain-grid" else "1")   # XCD-aware block order (default) / plain 3-D grid
     code, td, _ = DT[dt]
     pad = 1 if ks == 3 else 0
     Ho, Wo = (H + 2 * pad - ks) // s + 1, (W + 2 * pad - ks) // s + 1
