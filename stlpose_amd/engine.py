@@ -175,6 +175,7 @@ class Engine:
         # members per grouped launch (round 3 at 256 blocks: 1 / 2 / 4 / 8 = 15.87 / 15.64 / 16.03 / 17.51; 4 at 512 blocks: 15.36)
         self.wgrad_group = int(env("STLPOSE_WGRAD_GROUP", "4"))
         self.skip_wgrad = env("STLPOSE_SKIP_WGRAD", "0") != "0"   # calibration only (wrong numerics): no weight-gradient launches
+        self._poison = env("STLPOSE_POISON", "0") != "0"          # debug: planned buffers start as NaNs (see _alloc)
         self._stream = 0
         self._side = None
         self._stats_used = 0
@@ -192,6 +193,8 @@ class Engine:
         that merely lost its last Python reference must never go back to the caching allocator."""
         self.act_bytes += nbytes
         t = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        if self._poison:   # debug (STLPOSE_POISON=1): every planned buffer starts as NaNs, so that a kernel which reads a location
+            t.fill_(0xFF)  # nobody wrote -- and lets it reach a result -- shows up deterministically (0xFFFF / 0xFFFFFFFF = NaN)
         self._keep.append(t)
         return t
 
