@@ -73,7 +73,7 @@ def time_dominant_kernel(ts):
         evs.append((e0, e1, members))
     torch.cuda.synchronize()
     tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
-    esz = 2 if eng.dtype == capi.BF16 else 4
+    esz = 4 if eng.dtype == capi.F32 else 2
     flops = sum(2.0 * d.B * d.Ho * d.Wo * d.Co * d.Ci * 9 for _, _, ms in evs for d in ms)
     # h, dt and y read once, dw written once (split-K slabs are NOT algorithmic bytes)
     bytes_alg = sum((d.B * d.Hi * d.Wi * d.Ci + 2 * d.B * d.Ho * d.Wo * d.Co) * esz + d.Co * d.Ci * 9 * 4 for _, _, ms in evs for d in ms)

@@ -23,12 +23,21 @@ extern "C" {
 
 #define STL_F32 0
 #define STL_BF16 1
+#define STL_F16 2 /* IEEE half: the FORWARD tensors (raw conv outputs, materialised sums, MFMA operands, kernel-layout weights of
+                     the forward convs) of the mixed 16-bit mode -- BatchNorm bounds their range, and 10 mantissa bits instead of
+                     bf16's 7 cut the distance from the fp32 reference 6-8 x at the same bytes and MFMA rate.
+                     Gradients have no such bound and stay bf16: the backward kernels take the type of the forward tensors they
+                     read (BatchNorm-backward source y, mask_y, mask_z, the weight gradient's h) as a second dtype, `ydtype`. */
 #define STL_NSHARD 2 /* BatchNorm sum buffers are [STL_NSHARD][2*C] doubles (atomic de-contention).  Every consumer
                         reads all shards of its channels at the start of the launch (a dependent round trip in
                         front of ~800 launches per step): 8 / 4 / 2 / 1 shards = 16.25 / 15.89 / 15.65 / 15.87 ms */
 
 /* How a tensor is read ("normalise on load"): a conv / sum kernel applies the producing
  * BatchNorm (+ReLU) while staging its input, so BN never costs its own pass over HBM. */
+/* Two element types in one int argument: low byte = type of the gradient-side tensors, bits 8-15 = type of the forward-side
+ * tensors when it differs (0 = the same).  stl_head_backward: (dx, x); stl_weight_prep*: (data-gradient layouts, forward layouts). */
+#define STL_DT2(grad_dtype, fwd_dtype) ((grad_dtype) | ((fwd_dtype) << 8))
+
 #define STL_SRC_PLAIN 0 /* v = x                                              */
 #define STL_SRC_BN 1    /* v = [relu](a*x + b), a,b from batch or running stats  */
 #define STL_SRC_BNBWD 2 /* v = a*(dt - r1/n - yhat*r2/n): BatchNorm backward on load */
@@ -83,6 +92,8 @@ typedef struct stl_conv {
                               produces the last contribution to dz (HRnet.py:58-59,99-100). */
     void* src_out;         /* BNADD source: [B,Hi,Wi,Ci] dtype -- the transformed source (the block-end sum) is stored here, every
                               pixel by the one block whose tile owns it; NULL = not stored */
+    int32_t ydtype, pad_;       /* data gradient (BNBWD source) of the mixed mode: element type of the FORWARD tensors it reads -- src.y,
+                              mask_y, mask_z -- when it differs from dtype (STL_F16 with dtype STL_BF16); 0 = same as dtype */
 } stl_conv;
 int stl_conv_forward(const stl_conv* p, void* stream);
 /* Fill p->shape / p->TH / p->TW once (host-side tile search) so that launches are cheap. */
@@ -104,6 +115,8 @@ typedef struct stl_wgrad {
     stl_src h;
     stl_src g;
     float* partial; /* [nsplit][Co][ks*ks][Ci] */
+    int32_t ydtype; /* mixed mode: element type of the forward tensors h.x and g.y (STL_F16) when dtype (g.x = dt, the MFMA operands)
+                       is STL_BF16; 0 = same as dtype */
 } stl_wgrad;
 int stl_conv_wgrad(const stl_wgrad* p, void* stream);
 /* Up to STL_WGRAD_GROUP_MAX weight gradients of IDENTICAL geometry, tile, nsplit and gradient-source mode in one
@@ -137,12 +150,13 @@ int stl_fuse_forward(const stl_fuse* p, void* stream);
  * accumulates r1 = sum du, r2 = sum du*yhat into that term's rstats.  (aten::threshold_backward
  * + native_batch_norm_backward reductions.) */
 typedef struct stl_fuse_bwd {
-    int32_t dtype, B, H, W, C, ngrads, relu, nbn;
+    int32_t dtype, B, H, W, C, ngrads, relu, nbn; /* dtype: the gradients dz / du */
     const void* dz[4];
     const void* z;
     void* du;
     stl_src bn[4];    /* same-res BN terms (mode STL_SRC_BN): x = raw y, stats, gamma */
     double* rstats[4];
+    int32_t ydtype, pad_; /* mixed mode: element type of the forward tensors z and bn[].x (STL_F16 with dtype STL_BF16); 0 = dtype */
 } stl_fuse_bwd;
 int stl_fuse_backward(const stl_fuse_bwd* p, void* stream);
 
@@ -154,6 +168,7 @@ typedef struct stl_upbwd {
     void* dt;                         /* [B,H,W,C] */
     stl_src bn;
     double* rstats;
+    int32_t ydtype, pad_; /* mixed mode: element type of bn.x (STL_F16 with dtype STL_BF16); 0 = dtype */
 } stl_upbwd;
 int stl_upsample_backward(const stl_upbwd* p, void* stream);
 
@@ -300,10 +315,10 @@ int stl_reduce_slabs_range(const stl_reduce_range* r, void* stream);
  * between a bucket's reduction and its optimiser, and the host issues the slices, see train_step.py).  kind 0 = Adam,
  * 1 = SGD (v unused).  Reference: optimizer.step() after loss.backward(), 02_train.py:113-114. */
 typedef struct stl_optim_slice { int32_t kind, pad_; float* p; const float* g; float* m; float* v; int64_t n; const float* hyper; const int32_t* step; } stl_optim_slice;
-typedef struct stl_wprep_range { int32_t dtype, n, blk_base, nblocks; const float* master; void* wk; const stl_wprep* tab; } stl_wprep_range;
+typedef struct stl_wprep_range { int32_t dtype /* STL_DT2(data-gradient layouts, forward layouts) */, n, blk_base, nblocks; const float* master; void* wk; const stl_wprep* tab; } stl_wprep_range;
 typedef struct stl_patch { int32_t dtype, B, H, W, stride, pad_; const float* img; void* out; const float* mean3; const float* std3; } stl_patch;
 typedef struct stl_head { int32_t dtype, B, H, W, Ci, J; const void* x; const float* w; const float* bias; float* out; } stl_head;
-typedef struct stl_head_bwd { int32_t dtype, B, H, W, Ci, J, nblk, pad_; const void* x; const float* w; const float* dout; void* dx; float* partial; } stl_head_bwd;
+typedef struct stl_head_bwd { int32_t dtype /* STL_DT2(dx, x) */, B, H, W, Ci, J, nblk, pad_; const void* x; const float* w; const float* dout; void* dx; float* partial; } stl_head_bwd;
 typedef struct stl_op {
     int32_t kind;    /* STL_OP_*                                        */
     int32_t stream;  /* index into the streams array given to run()      */

@@ -15,6 +15,7 @@ LIB = os.path.join(HERE, "libstlpose_hip.so")
 # (source, object tag, extra flags): conv_core and wgrad are compiled once per dtype (-DSTL_DT) so that their kernel
 # instantiations build in parallel
 UNITS = [("capi.hip", "capi", []), ("conv_core.hip", "conv_core_bf16", ["-DSTL_DT=1"]), ("conv_core.hip", "conv_core_f32", ["-DSTL_DT=0"]),
+         ("conv_core.hip", "conv_core_f16", ["-DSTL_DT=3"]),
          ("wgrad.hip", "wgrad_bf16", ["-DSTL_DT=1"]), ("wgrad.hip", "wgrad_f32", ["-DSTL_DT=0"]), ("elementwise.hip", "elementwise", []),
          ("program.hip", "program", [])]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -11,7 +11,15 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STLPOSE_HIP_LIB") or os.path.join(_HERE, "libstlpose_hip.so")   # override: A/B of two builds
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
+
+
+def dt2(grad_dtype: int, fwd_dtype: int) -> int:
+    """STL_DT2: two element types in one int (low byte: gradient-side tensors, bits 8-15: forward-side tensors if different)."""
+    return grad_dtype | ((fwd_dtype if fwd_dtype != grad_dtype else 0) << 8)
+
+
+MIXED = dt2(BF16, F16)   # the mixed 16-bit mode: forward tensors f16, gradients bf16
 NSHARD = 2
 WGRAD_GROUP_MAX = 8
 SRC_PLAIN, SRC_BN, SRC_BNBWD, SRC_BNADD = 0, 1, 2, 3
@@ -28,13 +36,13 @@ class Conv(C.Structure):
                 ("Co", i32), ("ks", i32), ("stride", i32), ("stuff", i32), ("TH", i32), ("TW", i32), ("shape", i32),
                 ("src", Src), ("w", vp), ("out", vp), ("bias", vp), ("out_relu", i32), ("out_stats", vp),
                 ("addend", vp), ("mask_y", vp), ("mask_bn", Src), ("red", vp), ("mask_z", vp),
-                ("src_out", vp)]
+                ("src_out", vp), ("ydtype", i32), ("pad_", i32)]
 
 
 class Wgrad(C.Structure):
     _fields_ = [("dtype", i32), ("B", i32), ("Hi", i32), ("Wi", i32), ("Ci", i32), ("Ho", i32), ("Wo", i32),
                 ("Co", i32), ("ks", i32), ("stride", i32), ("TH", i32), ("TW", i32), ("nsplit", i32),
-                ("h", Src), ("g", Src), ("partial", vp)]
+                ("h", Src), ("g", Src), ("partial", vp), ("ydtype", i32)]
 
 
 class WgradGroup(C.Structure):
@@ -52,12 +60,12 @@ class Fuse(C.Structure):
 
 class FuseBwd(C.Structure):
     _fields_ = [("dtype", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("ngrads", i32), ("relu", i32),
-                ("nbn", i32), ("dz", vp * 4), ("z", vp), ("du", vp), ("bn", Src * 4), ("rstats", vp * 4)]
+                ("nbn", i32), ("dz", vp * 4), ("z", vp), ("du", vp), ("bn", Src * 4), ("rstats", vp * 4), ("ydtype", i32), ("pad_", i32)]
 
 
 class UpBwd(C.Structure):
     _fields_ = [("dtype", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("shift", i32),
-                ("du", vp), ("dt", vp), ("bn", Src), ("rstats", vp)]
+                ("du", vp), ("dt", vp), ("bn", Src), ("rstats", vp), ("ydtype", i32), ("pad_", i32)]
 
 
 class WPrep(C.Structure):

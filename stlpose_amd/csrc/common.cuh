@@ -4,11 +4,14 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <initializer_list>
+#include <type_traits>
 #include "../../include/stlpose_hip.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef _Float16 f16;   // STL_F16: forward activations of the mixed 16-bit mode (10 mantissa bits; gradients stay bf16 for range)
 
 struct alignas(16) V16 {
     uint32_t w[4];
@@ -44,11 +47,45 @@ struct ET<__bf16> {
     static constexpr int KV = 8;
     static constexpr int CK = 32;
 };
+template <>
+struct ET<f16> {
+    static constexpr int KV = 8;
+    static constexpr int CK = 32;
+};
+// dtype code (STL_F32 / STL_BF16 / STL_F16) of an element type
+template <typename T>
+constexpr int stl_code() { return sizeof(T) == 4 ? STL_F32 : (std::is_same<T, __bf16>::value ? STL_BF16 : STL_F16); }
 
 __device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
 __device__ __forceinline__ uint32_t f32_to_bf16(float f) {
     __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
     return (uint32_t)__builtin_bit_cast(unsigned short, h);
+}
+
+// two 16-bit values of one dword <-> two floats (T = __bf16 or f16): every 16-bit conversion of the kernels goes through these
+template <typename T>
+__device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi) {
+    if constexpr (std::is_same<T, __bf16>::value) {
+        lo = __uint_as_float(w << 16), hi = __uint_as_float(w & 0xFFFF0000u);
+    } else {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        const h2 h = __builtin_bit_cast(h2, w);
+        lo = (float)h[0], hi = (float)h[1];
+    }
+}
+template <typename T>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {   // round to nearest even, NaN-preserving
+    if constexpr (std::is_same<T, __bf16>::value) {
+        typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+        b2 r;
+        r[0] = (__bf16)lo, r[1] = (__bf16)hi;   // v_cvt_pk_bf16_f32
+        return __builtin_bit_cast(uint32_t, r);
+    } else {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        h2 r;
+        r[0] = (_Float16)lo, r[1] = (_Float16)hi;
+        return __builtin_bit_cast(uint32_t, r);
+    }
 }
 
 template <typename T>
@@ -61,10 +98,12 @@ __device__ __forceinline__ void unpack<float>(const V16& v, float* f) {
 template <>
 __device__ __forceinline__ void unpack<__bf16>(const V16& v, float* f) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        f[2 * i] = __uint_as_float(v.w[i] << 16);
-        f[2 * i + 1] = __uint_as_float(v.w[i] & 0xFFFF0000u);
-    }
+    for (int i = 0; i < 4; ++i) unpack2<__bf16>(v.w[i], f[2 * i], f[2 * i + 1]);
+}
+template <>
+__device__ __forceinline__ void unpack<f16>(const V16& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) unpack2<f16>(v.w[i], f[2 * i], f[2 * i + 1]);
 }
 template <typename T>
 __device__ __forceinline__ V16 pack(const float* f);
@@ -79,7 +118,14 @@ template <>
 __device__ __forceinline__ V16 pack<__bf16>(const float* f) {
     V16 v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v.w[i] = f32_to_bf16(f[2 * i]) | (f32_to_bf16(f[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) v.w[i] = pack2<__bf16>(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+template <>
+__device__ __forceinline__ V16 pack<f16>(const float* f) {
+    V16 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v.w[i] = pack2<f16>(f[2 * i], f[2 * i + 1]);
     return v;
 }
 // value as stored (rounded to T) -- so statistics see exactly what consumers will read
@@ -89,6 +135,8 @@ template <>
 __device__ __forceinline__ float round_to<float>(float f) { return f; }
 template <>
 __device__ __forceinline__ float round_to<__bf16>(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+template <>
+__device__ __forceinline__ float round_to<f16>(float f) { return (float)(_Float16)f; }
 
 __device__ __forceinline__ V16 zero16() {
     V16 v;
@@ -106,6 +154,10 @@ __device__ __forceinline__ void mma16(f32x4& acc, const V16& a, const V16& b);
 template <>
 __device__ __forceinline__ void mma16<__bf16>(f32x4& acc, const V16& a, const V16& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma16<f16>(f32x4& acc, const V16& a, const V16& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
 template <>
 __device__ __forceinline__ void mma16<float>(f32x4& acc, const V16& a, const V16& b) {
@@ -270,7 +322,7 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // "base<bf16,a0,a1,...>" for stl_note_kernel (built once per instantiation: function-local static in the launcher)
 template <typename T>
 static inline const char* stl_kname(char (&buf)[160], const char* base, std::initializer_list<int> args) {
-    int n = snprintf(buf, sizeof(buf), "%s<%s", base, sizeof(T) == 2 ? "bf16" : "f32");
+    int n = snprintf(buf, sizeof(buf), "%s<%s", base, sizeof(T) == 4 ? "f32" : (std::is_same<T, __bf16>::value ? "bf16" : "f16"));
     for (int a : args) n += snprintf(buf + n, sizeof(buf) - n, ",%d", a);
     snprintf(buf + n, sizeof(buf) - n, ">");
     return buf;

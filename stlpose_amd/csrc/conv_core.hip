@@ -26,6 +26,9 @@
 #ifndef STL_DT
 #define STL_DT 2
 #endif
+#define STL_HAS_F32 (STL_DT == 0 || STL_DT == 2)
+#define STL_HAS_BF16 (STL_DT == 1 || STL_DT == 2)   // + the C ABI entry points
+#define STL_HAS_F16 (STL_DT == 3 || STL_DT == 2)    // forward kernels of the mixed 16-bit mode (STL_F16)
 
 struct ConvK {
     stl_conv p;
@@ -47,6 +50,7 @@ struct ConvK {
 // 2 = everything else
 int stl_conv_backend_bf16(int path, const stl_conv& p, const ConvK& k, int shape, int nva, dim3 grid, size_t lds, hipStream_t st);
 int stl_conv_backend_f32(int path, const stl_conv& p, const ConvK& k, int shape, int nva, dim3 grid, size_t lds, hipStream_t st);
+int stl_conv_backend_f16(int path, const stl_conv& p, const ConvK& k, int shape, int nva, dim3 grid, size_t lds, hipStream_t st);
 
 namespace {
 
@@ -104,7 +108,8 @@ __device__ __forceinline__ int sdiv(int n, unsigned long long m) { return (int)(
 // ZM: the source is STL_SRC_BNADD (Q = true: second tensor on load): the staged value is the residual block end
 // z = ReLU(BN(x) + y); it is also written to p.src_out by the block that owns the pixel (tile interior, channel block 0).
 // PE: plain epilogue -- the launch has no bias / addend / mask operand (conv_common.inc, epilogue_apply).
-template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, bool PE, int OCC, int WR, bool ZM = false>
+// TY: element type of the FORWARD tensors a data gradient reads (src.y, mask_y, mask_z); T everywhere else.
+template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, bool PE, int OCC, int WR, bool ZM = false, typename TY = T>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const ConvK k) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTHR = 64 * WM * WN;
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
                 val = xform_bnadd<T>(val, rq[i], cs + chc, cs + k.cipad + chc, relu_lo);
                 if (ok && ((a_int >> i) & 1u)) stg16((char*)p.src_out + (size_t)(go[i] + k0) * sizeof(T), val);   // z, once per pixel
             } else if (Q)
-                val = xform_bnbwd<T>(val, rq[i], cs + chc, cs + k.cipad + chc, cs + 2 * k.cipad + chc);
+                val = xform_bnbwd<T, TY>(val, rq[i], cs + chc, cs + k.cipad + chc, cs + 2 * k.cipad + chc);
             else if (p.src.mode != STL_SRC_PLAIN)
                 val = xform_bn<T>(val, cs + chc, cs + k.cipad + chc, relu_lo);
             mask16(val, ok);  // zero padding applies AFTER the transform
@@ -414,13 +419,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
             if constexpr (EPRE) {
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
-                    epilogue_apply<T, NTW, BCO>(p, acc[mi], cm, pokv[mi], pixv[mi], n0, wn * NTW * 16, g, s0, s1, er[mi]);
+                    epilogue_apply<T, NTW, BCO, false, TY>(p, acc[mi], cm, pokv[mi], pixv[mi], n0, wn * NTW * 16, g, s0, s1, er[mi]);
             } else {   // register-tight instantiations: tile by tile
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) {
                     bool pok;
                     const size_t pix = out_pixel(vr0, c0, mi, pok);
-                    epilogue_tile<T, NTW, BCO, PE>(p, acc[mi], cm, pok, pix, n0, wn * NTW * 16, g, s0, s1);
+                    epilogue_tile<T, NTW, BCO, PE, TY>(p, acc[mi], cm, pok, pix, n0, wn * NTW * 16, g, s0, s1);
                 }
             }
         }
@@ -463,17 +468,17 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 #include "conv_ws.inc"
 #include "conv1x1.inc"
 
-template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, bool PE, int OCC = 1, int WR = -1, bool ZM = false>
+template <typename T, typename TY, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, bool PE, int OCC = 1, int WR = -1, bool ZM = false>
 int launch(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM, TY>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM>), grid, dim3(64 * WM * WN), lds, st, k);
+    hipLaunchKernelGGL((conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM, TY>), grid, dim3(64 * WM * WN), lds, st, k);
     static char nbuf[160];
-    static const char* nm = stl_kname<T>(nbuf, "conv_core_kernel", {KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM});
+    static const char* nm = stl_kname<T>(nbuf, "conv_core_kernel", {KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM, stl_code<TY>()});
     stl_note_kernel(nm, true);
     STL_LAUNCH_CHECK("conv_core");
     return 0;
@@ -500,35 +505,35 @@ constexpr Shape SHAPES[NSHAPES] = {{128, 64, 256, 0, 256, 9}, {512, 32, 512, 0, 
                                    {0, 0, 0, 0, 1, 0}, {0, 0, 0, 0, 1, 0}, {128, 64, 512, 1, 256, 9},
                                    {256, 32, 512, 0, 512, 3}, {128, 32, 512, 1, 256, 3}};
 
-template <typename T, int KS, bool Q, bool PE>
+template <typename T, typename TY, int KS, bool Q, bool PE>
 int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     switch (shape) {
         case 0:
-            if (nva <= 3) return launch<T, KS, 4, 1, 2, 4, 3, Q, PE>(k, grid, lds, st);
-            if (nva <= 9) return launch<T, KS, 4, 1, 2, 4, 9, Q, PE>(k, grid, lds, st);
+            if (nva <= 3) return launch<T, TY, KS, 4, 1, 2, 4, 3, Q, PE>(k, grid, lds, st);
+            if (nva <= 9) return launch<T, TY, KS, 4, 1, 2, 4, 9, Q, PE>(k, grid, lds, st);
             break;
         case 1:
-            if (nva <= 6) return launch<T, KS, 8, 1, 4, 2, 6, Q, PE>(k, grid, lds, st);
+            if (nva <= 6) return launch<T, TY, KS, 8, 1, 4, 2, 6, Q, PE>(k, grid, lds, st);
             break;
         case 2:   // the data-gradient form is sized for one block per CU (up to 256 VGPRs): a register cap alone spills
                   // (168 / 128 VGPRs: 49 / 160 spilled registers, 15.6 / 18.2 vs 14.64 ms per step in round 3)
-            if (nva <= 3) return launch<T, KS, 4, 2, 4, 2, 3, Q, PE, 1>(k, grid, lds, st);
+            if (nva <= 3) return launch<T, TY, KS, 4, 2, 4, 2, 3, Q, PE, 1>(k, grid, lds, st);
             break;
         case 8:   // three (data gradient) resp. four waves per SIMD, no spills
-            if (nva <= 3 && k.wres) return launch<T, KS, 8, 1, 2, 2, 3, Q, PE, 4, 1>(k, grid, lds, st);
-            if (nva <= 3) return launch<T, KS, 8, 1, 2, 2, 3, Q, PE, (Q ? 3 : 4)>(k, grid, lds, st);
+            if (nva <= 3 && k.wres) return launch<T, TY, KS, 8, 1, 2, 2, 3, Q, PE, 4, 1>(k, grid, lds, st);
+            if (nva <= 3) return launch<T, TY, KS, 8, 1, 2, 2, 3, Q, PE, (Q ? 3 : 4)>(k, grid, lds, st);
             break;
         case 4:
-            if (nva <= 3 && k.wres) return launch<T, KS, 4, 1, 2, 2, 3, Q, PE, 4, 1>(k, grid, lds, st);  // 113-123 VGPRs, no spills
-            if (nva <= 3) return launch<T, KS, 4, 1, 2, 2, 3, Q, PE, (Q ? 3 : 4)>(k, grid, lds, st);
-            if (nva <= 6) return launch<T, KS, 4, 1, 2, 2, 6, Q, PE, 3>(k, grid, lds, st);
+            if (nva <= 3 && k.wres) return launch<T, TY, KS, 4, 1, 2, 2, 3, Q, PE, 4, 1>(k, grid, lds, st);  // 113-123 VGPRs, no spills
+            if (nva <= 3) return launch<T, TY, KS, 4, 1, 2, 2, 3, Q, PE, (Q ? 3 : 4)>(k, grid, lds, st);
+            if (nva <= 6) return launch<T, TY, KS, 4, 1, 2, 2, 6, Q, PE, 3>(k, grid, lds, st);
             break;
         case 7:
-            if (nva <= 3) return launch_ws<T, KS, 2, 4, 3, Q>(k, grid, lds, st);
-            if (nva <= 9) return launch_ws<T, KS, 2, 4, 9, Q>(k, grid, lds, st);
+            if (nva <= 3) return launch_ws<T, TY, KS, 2, 4, 3, Q>(k, grid, lds, st);
+            if (nva <= 9) return launch_ws<T, TY, KS, 2, 4, 9, Q>(k, grid, lds, st);
             break;
         case 9:
-            if (nva <= 3) return launch_ws<T, KS, 2, 2, 3, Q>(k, grid, lds, st);
+            if (nva <= 3) return launch_ws<T, TY, KS, 2, 2, 3, Q>(k, grid, lds, st);
             break;
     }
     return stl_set_error("conv: no kernel variant for block shape %d with %d staging vectors per thread", shape, nva);
@@ -541,26 +546,40 @@ static bool bnadd_shape_ok(int shape, int nva) { return nva <= 3 && (shape == 0 
 template <typename T>
 int dispatch_bnadd(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     if (nva <= 3) switch (shape) {
-        case 0: return launch<T, 3, 4, 1, 2, 4, 3, true, true, 1, -1, true>(k, grid, lds, st);
-        case 2: return launch<T, 3, 4, 2, 4, 2, 3, true, true, 1, -1, true>(k, grid, lds, st);
-        case 4: return launch<T, 3, 4, 1, 2, 2, 3, true, true, 3, -1, true>(k, grid, lds, st);
-        case 8: return launch<T, 3, 8, 1, 2, 2, 3, true, true, 3, -1, true>(k, grid, lds, st);
+        case 0: return launch<T, T, 3, 4, 1, 2, 4, 3, true, true, 1, -1, true>(k, grid, lds, st);
+        case 2: return launch<T, T, 3, 4, 2, 4, 2, 3, true, true, 1, -1, true>(k, grid, lds, st);
+        case 4: return launch<T, T, 3, 4, 1, 2, 2, 3, true, true, 3, -1, true>(k, grid, lds, st);
+        case 8: return launch<T, T, 3, 8, 1, 2, 2, 3, true, true, 3, -1, true>(k, grid, lds, st);
     }
     return stl_set_error("conv: no block-end (BNADD) variant for block shape %d with %d staging vectors per thread", shape, nva);
 }
 
-template <typename T>
+template <typename T, typename TY>
 int conv_backend(int path, const stl_conv& p, const ConvK& k, int shape, int nva, dim3 grid, size_t lds, hipStream_t st) {
-    if (path == 0) return run_1x1<T>(p, st);
-    if (path == 1) return dispatch_bnadd<T>(shape, nva, k, grid, lds, st);
     const bool q = p.src.mode == STL_SRC_BNBWD;
+    if constexpr (!std::is_same<T, TY>::value) {   // mixed mode: only data gradients read forward tensors of another type
+        if (!q) return stl_set_error("conv: ydtype differs from dtype, but the launch is not a data gradient (BNBWD source)");
+    }
+    if constexpr (std::is_same<T, f16>::value) {   // f16 tensors exist in the forward pass only
+        if (q) return stl_set_error("conv: STL_F16 is a forward-tensor type; gradients are bf16 (dtype STL_BF16 + ydtype STL_F16)");
+    }
+    constexpr bool FWD = std::is_same<T, TY>::value, BWD = !std::is_same<T, f16>::value;
+    if (path == 0) return run_1x1<T, TY>(p, st);
+    if (path == 1) {
+        if constexpr (FWD) return dispatch_bnadd<T>(shape, nva, k, grid, lds, st);
+    }
     const bool plain = !p.bias && !p.addend && !p.mask_y && !p.mask_z && !p.red;   // forward convs of the pose network
     if (p.ks == 3) {
-        if (q) return dispatch<T, 3, true, false>(shape, nva, k, grid, lds, st);
-        return plain ? dispatch<T, 3, false, true>(shape, nva, k, grid, lds, st) : dispatch<T, 3, false, false>(shape, nva, k, grid, lds, st);
+        if (q) {
+            if constexpr (BWD) return dispatch<T, TY, 3, true, false>(shape, nva, k, grid, lds, st);
+        }
+        if constexpr (FWD) return plain ? dispatch<T, T, 3, false, true>(shape, nva, k, grid, lds, st) : dispatch<T, T, 3, false, false>(shape, nva, k, grid, lds, st);
     }
-    if (q) return dispatch<T, 1, true, false>(shape, nva, k, grid, lds, st);
-    return plain ? dispatch<T, 1, false, true>(shape, nva, k, grid, lds, st) : dispatch<T, 1, false, false>(shape, nva, k, grid, lds, st);
+    if (q) {
+        if constexpr (BWD) return dispatch<T, TY, 1, true, false>(shape, nva, k, grid, lds, st);
+    }
+    if constexpr (FWD) return plain ? dispatch<T, T, 1, false, true>(shape, nva, k, grid, lds, st) : dispatch<T, T, 1, false, false>(shape, nva, k, grid, lds, st);
+    return stl_set_error("conv: no kernel for this dtype combination");
 }
 
 struct Plan {
@@ -654,18 +673,25 @@ Plan choose_plan(const stl_conv& p, int ck) {
 
 }  // namespace
 
-#if STL_DT != 0
+static int ydtype_of(const stl_conv& p) { return (p.dtype == STL_BF16 && p.ydtype == STL_F16) ? STL_F16 : p.dtype; }   // 0 = same as dtype
+#if STL_HAS_BF16
 int stl_conv_backend_bf16(int path, const stl_conv& p, const ConvK& k, int shape, int nva, dim3 grid, size_t lds, hipStream_t st) {
-    return conv_backend<__bf16>(path, p, k, shape, nva, grid, lds, st);
+    if (ydtype_of(p) == STL_F16) return conv_backend<__bf16, f16>(path, p, k, shape, nva, grid, lds, st);   // mixed-mode data gradient
+    return conv_backend<__bf16, __bf16>(path, p, k, shape, nva, grid, lds, st);
 }
 #endif
-#if STL_DT != 1
+#if STL_HAS_F32
 int stl_conv_backend_f32(int path, const stl_conv& p, const ConvK& k, int shape, int nva, dim3 grid, size_t lds, hipStream_t st) {
-    return conv_backend<float>(path, p, k, shape, nva, grid, lds, st);
+    return conv_backend<float, float>(path, p, k, shape, nva, grid, lds, st);
+}
+#endif
+#if STL_HAS_F16
+int stl_conv_backend_f16(int path, const stl_conv& p, const ConvK& k, int shape, int nva, dim3 grid, size_t lds, hipStream_t st) {
+    return conv_backend<f16, f16>(path, p, k, shape, nva, grid, lds, st);
 }
 #endif
 
-#if STL_DT != 0   // the C ABI entry points live in the bf16 (or the only) unit
+#if STL_HAS_BF16   // the C ABI entry points live in the bf16 (or the only) unit
 extern "C" int stl_debug_conv_stamps(long long* host12) {
     return hipMemcpyFromSymbol(host12, HIP_SYMBOL(g_stamps), 14 * sizeof(long long)) == hipSuccess ? 0 : stl_set_error("stamps: copy failed");
 }
@@ -675,9 +701,9 @@ extern "C" int stl_debug_conv_stamps2(long long* host64) {
 
 extern "C" int stl_conv_plan(stl_conv* pp) {
     stl_conv& p = *pp;
-    STL_CHECK(p.dtype == STL_F32 || p.dtype == STL_BF16, "conv_plan: bad dtype");
+    STL_CHECK(p.dtype == STL_F32 || p.dtype == STL_BF16 || p.dtype == STL_F16, "conv_plan: bad dtype");
     STL_CHECK((p.ks == 1 || p.ks == 3) && (p.stride == 1 || p.stride == 2) && p.Ci > 0 && p.Co > 0, "conv_plan: bad geometry");
-    const int ck = p.dtype == STL_BF16 ? 32 : 16;
+    const int ck = p.dtype == STL_F32 ? 16 : 32;
     Plan plan = choose_plan(p, ck);
     STL_CHECK(plan.shape >= 0, "conv_plan: no tile fits LDS for %dx%d ks %d stride %d Ci %d", p.Ho, p.Wo, p.ks, p.stride, p.Ci);
     p.shape = plan.shape, p.TH = plan.TH, p.TW = plan.TW;
@@ -694,12 +720,13 @@ extern "C" int stl_conv_bnadd_ok(const stl_conv* pp) {
 
 extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     const stl_conv& p = *pp;
-    STL_CHECK(p.dtype == STL_F32 || p.dtype == STL_BF16, "conv: bad dtype %d", p.dtype);
+    STL_CHECK(p.dtype == STL_F32 || p.dtype == STL_BF16 || p.dtype == STL_F16, "conv: bad dtype %d", p.dtype);
+    STL_CHECK(p.ydtype == 0 || p.ydtype == p.dtype || (p.dtype == STL_BF16 && p.ydtype == STL_F16), "conv: ydtype %d does not go with dtype %d", p.ydtype, p.dtype);
     STL_CHECK(p.ks == 1 || p.ks == 3, "conv: ks must be 1 or 3 (got %d)", p.ks);
     STL_CHECK(p.stride == 1 || p.stride == 2, "conv: stride must be 1 or 2");
     STL_CHECK(!(p.stuff && p.stride != 1), "conv: stuff requires stride 1");
     STL_CHECK(!(p.ks == 1 && (p.stride != 1 || p.stuff)), "conv: 1x1 must be stride 1");
-    const int kv = p.dtype == STL_BF16 ? 8 : 4, ck = 4 * kv;
+    const int kv = p.dtype == STL_F32 ? 4 : 8, ck = 4 * kv;
     STL_CHECK(p.Ci % kv == 0 && p.Ci > 0, "conv: Ci=%d must be a multiple of %d", p.Ci, kv);
     STL_CHECK(p.Co % 8 == 0 && p.Co > 0, "conv: Co=%d must be a multiple of 8", p.Co);
     STL_CHECK(p.B > 0 && p.Hi > 0 && p.Wi > 0 && p.Ho > 0 && p.Wo > 0, "conv: empty tensor");
@@ -727,7 +754,7 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     STL_CHECK(!p.red || p.mask_y, "conv: red needs mask_y");
     STL_CHECK(!p.mask_y || (p.mask_bn.gamma && p.mask_bn.beta && (p.mask_bn.stats || (p.mask_bn.rmean && p.mask_bn.rvar))), "conv: mask BN incomplete");
 
-    const auto backend = p.dtype == STL_BF16 ? stl_conv_backend_bf16 : stl_conv_backend_f32;
+    const auto backend = p.dtype == STL_BF16 ? stl_conv_backend_bf16 : (p.dtype == STL_F16 ? stl_conv_backend_f16 : stl_conv_backend_f32);
     if (use_1x1(p))  // wide 1x1 convolutions: streaming GEMM kernel (conv1x1.inc)
         return backend(0, p, ConvK{}, 0, 0, dim3(1), 0, (hipStream_t)stream);
 
@@ -793,4 +820,4 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     return backend(zm ? 1 : 2, p, k, plan.shape, nva, grid, lds, st);
 }
-#endif   // STL_DT != 0
+#endif   // STL_HAS_BF16

@@ -8,7 +8,7 @@ namespace {
 template <typename T>
 __device__ __forceinline__ void load8(const void* base, size_t elem, float* f) {
     if constexpr (sizeof(T) == 2) {
-        unpack<__bf16>(ldg16((const char*)base + elem * 2), f);
+        unpack<T>(ldg16((const char*)base + elem * 2), f);
     } else {
         unpack<float>(ldg16((const char*)base + elem * 4), f);
         unpack<float>(ldg16((const char*)base + elem * 4 + 16), f + 4);
@@ -17,7 +17,7 @@ __device__ __forceinline__ void load8(const void* base, size_t elem, float* f) {
 template <typename T>
 __device__ __forceinline__ void store8(void* base, size_t elem, const float* f) {
     if constexpr (sizeof(T) == 2) {
-        stg16((char*)base + elem * 2, pack<__bf16>(f));
+        stg16((char*)base + elem * 2, pack<T>(f));
     } else {
         stg16((char*)base + elem * 4, pack<float>(f));
         stg16((char*)base + elem * 4 + 16, pack<float>(f + 4));
@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(const stl_fuse p) {
 }
 
 // ---------------------------------------------------------------- fuse backward
-template <typename T>
+// T: the gradients dz / du; TY: the forward tensors z and bn[].x (f16 in the mixed mode)
+template <typename T, typename TY = T>
 __global__ void fuse_bwd_kernel(const stl_fuse_bwd p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = p.C, VPC = C >> 3;
@@ -133,7 +134,7 @@ __global__ void fuse_bwd_kernel(const stl_fuse_bwd p) {
         }
         if (p.relu) {
             float z[8];
-            load8<T>(p.z, off, z);
+            load8<TY>(p.z, off, z);
 #pragma unroll
             for (int j = 0; j < 8; ++j) d[j] = z[j] > 0.f ? d[j] : 0.f;
         }
@@ -148,7 +149,7 @@ __global__ void fuse_bwd_kernel(const stl_fuse_bwd p) {
             for (int t = 0; t < 4; ++t) {
                 if (t < p.nbn) {
                     float y[8];
-                    load8<T>(p.bn[t].x, off, y);
+                    load8<TY>(p.bn[t].x, off, y);
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
                         acc[1 + t][j] += d[j] * (y[j] - mu[(t * 2) * C + c0 + j]) * mu[(t * 2 + 1) * C + c0 + j];
@@ -176,7 +177,7 @@ __global__ void fuse_bwd_kernel(const stl_fuse_bwd p) {
 }
 
 // ---------------------------------------------------------------- upsample backward
-template <typename T>
+template <typename T, typename TY = T>
 __global__ void upsample_bwd_kernel(const stl_upbwd p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = p.C, VPC = C >> 3;
@@ -216,7 +217,7 @@ __global__ void upsample_bwd_kernel(const stl_upbwd p) {
         for (int j = 0; j < 8; ++j) s[j] = round_to<T>(s[j]);
         store8<T>(p.dt, pi * C + c0, s);
         float yv[8];
-        load8<T>(p.bn.x, pi * C + c0, yv);
+        load8<TY>(p.bn.x, pi * C + c0, yv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             acc[0][j] += s[j];
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const void* x, const floa
 // of the pixels, accumulators kept across the block's chunks, one cross-wave reduction at the end).  The scalar LDS
 // loop this replaces (561 outputs x 256 pixels x 2 reads per chunk) made the head the slowest launch per byte of the
 // step: 78 us at the very start of backward, where nothing else can run.
-template <typename T, int J>
+template <typename T, int J, typename TY = T>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const void* x, const float* w, const float* dout, void* dx,
                                                        float* partial, int B, int HW, int Ci) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const void* x, const floa
         for (int c0 = 0; c0 < Ci; c0 += 8) {
             float f[8], gx[8];
             if (pi < P) {
-                load8<T>(x, pi * Ci + c0, f);
+                load8<TY>(x, pi * Ci + c0, f);
             } else {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) f[q] = 0.f;
@@ -540,12 +541,21 @@ __device__ __forceinline__ void store_vec4(__bf16* dst, const __bf16* v) {
     u.y = (uint32_t)__builtin_bit_cast(unsigned short, v[2]) | ((uint32_t)__builtin_bit_cast(unsigned short, v[3]) << 16);
     *reinterpret_cast<uint2*>(dst) = u;
 }
+__device__ __forceinline__ void store_vec4(f16* dst, const f16* v) {
+    uint2 u;
+    u.x = (uint32_t)__builtin_bit_cast(unsigned short, v[0]) | ((uint32_t)__builtin_bit_cast(unsigned short, v[1]) << 16);
+    u.y = (uint32_t)__builtin_bit_cast(unsigned short, v[2]) | ((uint32_t)__builtin_bit_cast(unsigned short, v[3]) << 16);
+    *reinterpret_cast<uint2*>(dst) = u;
+}
 __device__ __forceinline__ void store_vec4(float* dst, const float* v) {
     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-template <typename T>
+// T: element type of the data-gradient layouts; TF: of the forward layouts (f16 in the mixed mode, else T)
+template <typename T, typename TF = T>
 __global__ __launch_bounds__(256) void weight_prep_kernel(const float* master, T* wk, const stl_wprep* tab, int n, int blk_base) {
+    static_assert(sizeof(T) == sizeof(TF), "both layouts live in one buffer of equal-width elements");
+    TF* wkf = reinterpret_cast<TF*>(wk);
     const int bx = blockIdx.x + blk_base;  // tab points at the first entry of the range, blk0 values are table-absolute
     const int ei = find_entry(&tab[0].blk0, sizeof(stl_wprep) / 4, n, bx);
     const stl_wprep e = tab[ei];
@@ -573,14 +583,15 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* master, T
             }
             __syncthreads();
             T v[4];
+            TF vf[4];
             // forward layout [co][tap][ci]: task = (row = co_l * t + tap, 4 ci); taps are 1 or 9 (constant divisors)
             const int q4 = nci >> 2;
             for (int i = threadIdx.x; i < nco * t * q4; i += 256) {
                 const int row = q4 == 8 ? i >> 3 : i / q4, c4 = (i - row * q4) * 4;
                 const int r = t == 9 ? row / 9 : (t == 1 ? row : row / t), tap = row - r * t;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (T)st[r * pitch + (c4 + j) * t + tap];
-                store_vec4(wk + e.fwd_off + ((int64_t)(co0 + r) * t + tap) * e.Ci + ci0 + c4, v);
+                for (int j = 0; j < 4; ++j) vf[j] = (TF)st[r * pitch + (c4 + j) * t + tap];
+                store_vec4(wkf + e.fwd_off + ((int64_t)(co0 + r) * t + tap) * e.Ci + ci0 + c4, vf);
             }
             if (e.bwd_off >= 0) {   // data-gradient layout [ci][flipped tap][co]: task = (row = ci_l * t + tapf, 4 co)
                 const int p4 = nco >> 2;
@@ -601,9 +612,9 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* master, T
         const int co = (int)(i / (e.Ci * t)), rem = (int)(i - (int64_t)co * e.Ci * t), ci = rem / t, tap = rem - ci * t;
         const float v = master[e.src_off + i];
         if (e.patch)
-            wk[e.fwd_off + (int64_t)co * e.Cip + tap * e.Ci + ci] = (T)v;
+            wkf[e.fwd_off + (int64_t)co * e.Cip + tap * e.Ci + ci] = (TF)v;
         else
-            wk[e.fwd_off + ((int64_t)co * t + tap) * e.Cip + ci] = (T)v;
+            wkf[e.fwd_off + ((int64_t)co * t + tap) * e.Cip + ci] = (TF)v;
         if (e.bwd_off >= 0) wk[e.bwd_off + ((int64_t)ci * t + (t - 1 - tap)) * e.Co + co] = (T)v;
     }
 }
@@ -963,10 +974,13 @@ extern "C" int stl_fuse_forward(const stl_fuse* pp, void* stream) {
     const size_t total = (size_t)p.B * p.H * p.W * (p.C / 8);
     STL_CHECK(total * 8 < (1ull << 31), "fuse: tensors of 2^31 or more elements are not supported");
     const size_t lds = (size_t)p.nterms * 2 * p.C * 4;
+    const dim3 grid(nblocks_for(total, 256, 2048));
     if (p.dtype == STL_BF16)
-        hipLaunchKernelGGL(fuse_fwd_kernel<__bf16>, dim3(nblocks_for(total, 256, getenv("STL_FUSEF_BLOCKS") ? atoi(getenv("STL_FUSEF_BLOCKS")) : 2048)), dim3(256), lds, ST, p);
+        hipLaunchKernelGGL(fuse_fwd_kernel<__bf16>, grid, dim3(256), lds, ST, p);
+    else if (p.dtype == STL_F16)
+        hipLaunchKernelGGL(fuse_fwd_kernel<f16>, grid, dim3(256), lds, ST, p);
     else
-        hipLaunchKernelGGL(fuse_fwd_kernel<float>, dim3(nblocks_for(total, 256, getenv("STL_FUSEF_BLOCKS") ? atoi(getenv("STL_FUSEF_BLOCKS")) : 2048)), dim3(256), lds, ST, p);
+        hipLaunchKernelGGL(fuse_fwd_kernel<float>, grid, dim3(256), lds, ST, p);
     STL_LAUNCH_CHECK("fuse_forward");
     return 0;
 }
@@ -988,9 +1002,12 @@ extern "C" int stl_fuse_backward(const stl_fuse_bwd* pp, void* stream) {
     // contention with co-running kernels); the 113 MB layer1 tensors need more loads in flight
     int cap = (int)(total / (size_t)(bd * 16));
     cap = cap < 256 ? 256 : (cap > 1024 ? 1024 : cap);
-    int nb = nblocks_for(total, bd, getenv("STL_FUSE_BLOCKS") ? atoi(getenv("STL_FUSE_BLOCKS")) : cap);
+    int nb = nblocks_for(total, bd, cap);
     const size_t lds = (size_t)(p.nbn > 0 ? p.nbn : 1) * 2 * p.C * 4 + (size_t)bd * 2 * 8 * 4;
-    if (p.dtype == STL_BF16)
+    STL_CHECK(p.ydtype == 0 || p.ydtype == p.dtype || (p.dtype == STL_BF16 && p.ydtype == STL_F16), "fuse_bwd: ydtype %d does not go with dtype %d", p.ydtype, p.dtype);
+    if (p.dtype == STL_BF16 && p.ydtype == STL_F16)
+        hipLaunchKernelGGL((fuse_bwd_kernel<__bf16, f16>), dim3(nb), dim3(bd), lds, ST, p);
+    else if (p.dtype == STL_BF16)
         hipLaunchKernelGGL(fuse_bwd_kernel<__bf16>, dim3(nb), dim3(bd), lds, ST, p);
     else
         hipLaunchKernelGGL(fuse_bwd_kernel<float>, dim3(nb), dim3(bd), lds, ST, p);
@@ -1009,9 +1026,12 @@ extern "C" int stl_upsample_backward(const stl_upbwd* pp, void* stream) {
     // contention with co-running kernels); the 113 MB layer1 tensors need more loads in flight
     int cap = (int)(total / (size_t)(bd * 16));
     cap = cap < 256 ? 256 : (cap > 1024 ? 1024 : cap);
-    int nb = nblocks_for(total, bd, getenv("STL_FUSE_BLOCKS") ? atoi(getenv("STL_FUSE_BLOCKS")) : cap);
+    int nb = nblocks_for(total, bd, cap);
     const size_t lds = (size_t)2 * p.C * 4 + (size_t)bd * 2 * 8 * 4;
-    if (p.dtype == STL_BF16)
+    STL_CHECK(p.ydtype == 0 || p.ydtype == p.dtype || (p.dtype == STL_BF16 && p.ydtype == STL_F16), "upsample_bwd: ydtype %d does not go with dtype %d", p.ydtype, p.dtype);
+    if (p.dtype == STL_BF16 && p.ydtype == STL_F16)
+        hipLaunchKernelGGL((upsample_bwd_kernel<__bf16, f16>), dim3(nb), dim3(bd), lds, ST, p);
+    else if (p.dtype == STL_BF16)
         hipLaunchKernelGGL(upsample_bwd_kernel<__bf16>, dim3(nb), dim3(bd), lds, ST, p);
     else
         hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(nb), dim3(bd), lds, ST, p);
@@ -1027,6 +1047,8 @@ extern "C" int stl_patch3x3(int dtype, const float* img, void* out, int B, int H
     const size_t total = (size_t)B * Ho * Wo * 4;
     if (dtype == STL_BF16)
         hipLaunchKernelGGL(patch_kernel<__bf16>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, img, out, B, H, W, Ho, Wo, stride, mean3, std3);
+    else if (dtype == STL_F16)
+        hipLaunchKernelGGL(patch_kernel<f16>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, img, out, B, H, W, Ho, Wo, stride, mean3, std3);
     else
         hipLaunchKernelGGL(patch_kernel<float>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, img, out, B, H, W, Ho, Wo, stride, mean3, std3);
     STL_LAUNCH_CHECK("patch3x3");
@@ -1042,14 +1064,17 @@ extern "C" int stl_head_forward(int dtype, const void* x, const float* w, const 
     const dim3 grid(nblocks_for(P));
 #define HF(T, JJ) hipLaunchKernelGGL((head_fwd_kernel<T, JJ>), grid, dim3(256), lds, ST, x, w, bias, out, B, H * W, Ci)
     if (dtype == STL_BF16) { if (J == 17) HF(__bf16, 17); else HF(__bf16, 16); }
+    else if (dtype == STL_F16) { if (J == 17) HF(f16, 17); else HF(f16, 16); }
     else { if (J == 17) HF(float, 17); else HF(float, 16); }
 #undef HF
     STL_LAUNCH_CHECK("head_forward");
     return 0;
 }
 
-extern "C" int stl_head_backward(int dtype, const void* x, const float* w, const float* dout, void* dx, float* partial,
+extern "C" int stl_head_backward(int dtype2, const void* x, const float* w, const float* dout, void* dx, float* partial,
                                  int nblk, int B, int H, int W, int Ci, int J, void* stream) {
+    const int dtype = dtype2 & 0xff, ydtype = (dtype2 >> 8) & 0xff;   // STL_DT2(type of dx, type of x)
+    STL_CHECK(ydtype == 0 || ydtype == dtype || (dtype == STL_BF16 && ydtype == STL_F16), "head_bwd: x type %d does not go with dx type %d", ydtype, dtype);
     STL_CHECK(J == 17 || J == 16, "head_bwd: J=%d unsupported", J);
     STL_CHECK(Ci % 8 == 0 && J * Ci + J <= 1024, "head_bwd: Ci=%d", Ci);
     STL_CHECK(nblk >= 1, "head_bwd: nblk");
@@ -1063,11 +1088,14 @@ extern "C" int stl_head_backward(int dtype, const void* x, const float* w, const
         hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<__bf16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<float, 17>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<float, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<__bf16, 17, f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<__bf16, 16, f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-#define HB(T, JJ) hipLaunchKernelGGL((head_bwd_kernel<T, JJ>), dim3(nblk), dim3(256), lds, ST, x, w, dout, dx, partial, B, H * W, Ci)
-    if (dtype == STL_BF16) { if (J == 17) HB(__bf16, 17); else HB(__bf16, 16); }
-    else { if (J == 17) HB(float, 17); else HB(float, 16); }
+#define HB(T, JJ, TY) hipLaunchKernelGGL((head_bwd_kernel<T, JJ, TY>), dim3(nblk), dim3(256), lds, ST, x, w, dout, dx, partial, B, H * W, Ci)
+    if (dtype == STL_BF16 && ydtype == STL_F16) { if (J == 17) HB(__bf16, 17, f16); else HB(__bf16, 16, f16); }
+    else if (dtype == STL_BF16) { if (J == 17) HB(__bf16, 17, __bf16); else HB(__bf16, 16, __bf16); }
+    else { if (J == 17) HB(float, 17, float); else HB(float, 16, float); }
 #undef HB
     STL_LAUNCH_CHECK("head_backward");
     return 0;
@@ -1113,21 +1141,22 @@ extern "C" int stl_flip_merge(const float* a, const float* bflip, float* out, co
     return 0;
 }
 
-extern "C" int stl_weight_prep(int dtype, const float* master, void* wk, const stl_wprep* tab, int n, int nblocks, void* stream) {
+extern "C" int stl_weight_prep(int dtype2, const float* master, void* wk, const stl_wprep* tab, int n, int nblocks, void* stream) {
     if (n == 0) return 0;
-    if (dtype == STL_BF16)
-        hipLaunchKernelGGL(weight_prep_kernel<__bf16>, dim3(nblocks), dim3(256), 0, ST, master, (__bf16*)wk, tab, n, 0);
-    else
-        hipLaunchKernelGGL(weight_prep_kernel<float>, dim3(nblocks), dim3(256), 0, ST, master, (float*)wk, tab, n, 0);
-    STL_LAUNCH_CHECK("weight_prep");
-    return 0;
+    return stl_weight_prep_range(dtype2, master, wk, tab, n, 0, nblocks, stream);
 }
 
-extern "C" int stl_weight_prep_range(int dtype, const float* master, void* wk, const stl_wprep* tab, int n, int blk_base, int nblocks,
+extern "C" int stl_weight_prep_range(int dtype2, const float* master, void* wk, const stl_wprep* tab, int n, int blk_base, int nblocks,
                                      void* stream) {
     if (n == 0 || nblocks == 0) return 0;
     STL_CHECK(master && wk && tab && n > 0 && blk_base >= 0 && nblocks > 0, "weight_prep_range: bad arguments");
-    if (dtype == STL_BF16)
+    const int dtype = dtype2 & 0xff, fdtype = (dtype2 >> 8) & 0xff;   // STL_DT2(type of the data-gradient layouts, type of the forward layouts)
+    STL_CHECK(fdtype == 0 || fdtype == dtype || (dtype == STL_BF16 && fdtype == STL_F16), "weight_prep: forward type %d does not go with %d", fdtype, dtype);
+    if (dtype == STL_BF16 && fdtype == STL_F16)
+        hipLaunchKernelGGL((weight_prep_kernel<__bf16, f16>), dim3(nblocks), dim3(256), 0, ST, master, (__bf16*)wk, tab, n, blk_base);
+    else if (dtype == STL_F16)
+        hipLaunchKernelGGL((weight_prep_kernel<f16, f16>), dim3(nblocks), dim3(256), 0, ST, master, (f16*)wk, tab, n, blk_base);
+    else if (dtype == STL_BF16)
         hipLaunchKernelGGL(weight_prep_kernel<__bf16>, dim3(nblocks), dim3(256), 0, ST, master, (__bf16*)wk, tab, n, blk_base);
     else
         hipLaunchKernelGGL(weight_prep_kernel<float>, dim3(nblocks), dim3(256), 0, ST, master, (float*)wk, tab, n, blk_base);

@@ -144,7 +144,8 @@ __device__ __forceinline__ V16 frag_at<float>(const uint32_t* addr, int off) {
 // needs 4 * TAPS = 36, no reduction, and leaves room for TWO tiles of staged loads per thread: the loads of tile
 // t + 2 are issued while tile t is multiplied, so a tile's memory round trip (~2 us when 256 blocks load at once)
 // is covered by two iterations instead of being exposed once per tile (it was ~80 % of the K loop).
-template <typename T, int KS, int NVH, bool GQ, int TPX, int OCC, int NW>
+// TY: element type of the FORWARD tensors (h.x, g.y); T: the gradient dt = g.x and the MFMA operands
+template <typename T, int KS, int NVH, bool GQ, int TPX, int OCC, int NW, typename TY = T>
 __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KV = ET<T>::KV, TAPS = KS * KS;
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
 #pragma unroll
         for (int i = 0; i < NVG; ++i) {
             V16 val = rgv[S][i];
-            if (GQ) val = xform_bnbwd<T>(val, rgq[S][i], cgc + cl, cgc + 32 + cl, cgc + 64 + cl);
+            if (GQ) val = xform_bnbwd<T, TY>(val, rgq[S][i], cgc + cl, cgc + 32 + cl, cgc + 64 + cl);
             mask16(val, (okm[S] >> i) & 1u);
             const int v = tid + i * NT;
             *reinterpret_cast<V16*>(sG + (v / VPX) * PS + g_part * 16) = val;
@@ -293,7 +294,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
             // as a whole leaves its load pending on that path, and the wait-count pass then drains EVERY outstanding
             // load (the other set's too) in front of the next instruction that overwrites the register
             V16 val = rhv[S][i];
-            if (io.h.mode == STL_SRC_BN) val = xform_bn<T>(val, chc + cl, chc + 32 + cl, relu_lo);
+            if (io.h.mode == STL_SRC_BN) val = xform_bn<T, TY>(val, chc + cl, chc + 32 + cl, relu_lo);
+            else val = xform_cvt<T, TY>(val);
             mask16(val, (okm[S] >> (NVG + i)) & 1u);
             const int v = tid + i * NT;
             if (h_rc[i] >= 0) *reinterpret_cast<V16*>(sH + (v / VPX) * PS + g_part * 16) = val;
@@ -419,18 +421,18 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
 }
 
 
-template <typename T, int KS, int NVH, bool GQ, int TPX = 128, int NW = 4>
+template <typename T, typename TY, int KS, int NVH, bool GQ, int TPX = 128, int NW = 4>
 int launch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
     constexpr int OCC = (NVH * NW <= 24 && TPX == 128 && sizeof(T) == 2) ? 2 : 1;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, KS, NVH, GQ, TPX, OCC, NW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, KS, NVH, GQ, TPX, OCC, NW, TY>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((wgrad_kernel<T, KS, NVH, GQ, TPX, OCC, NW>), grid, dim3(64 * NW), lds, st, k);
+    hipLaunchKernelGGL((wgrad_kernel<T, KS, NVH, GQ, TPX, OCC, NW, TY>), grid, dim3(64 * NW), lds, st, k);
     static char nbuf[160];
-    static const char* nm = stl_kname<T>(nbuf, "wgrad_kernel", {KS, NVH, GQ, TPX, OCC, NW});
+    static const char* nm = stl_kname<T>(nbuf, "wgrad_kernel", {KS, NVH, GQ, TPX, OCC, NW, stl_code<TY>()});
     stl_note_kernel(nm, true);
     STL_LAUNCH_CHECK("conv_wgrad");
     return 0;
@@ -445,7 +447,7 @@ int launch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
 // MFMAs per barrier pair, and there is no cross-wave reduction: every wave writes its own quadrant
 // of the slab straight from the accumulators.  LDS pixel stride 160 B (128 B data + 32 B pad: the
 // four rows of a transposed 16-lane read fall into disjoint bank groups).
-template <typename T, int KS, int NVH, bool GQ, int TPX>
+template <typename T, int KS, int NVH, bool GQ, int TPX, typename TY = T>
 __global__ __launch_bounds__(256) void wgrad64_kernel(const WgK k) {
     static_assert(sizeof(T) == 2, "bf16 only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(const WgK k) {
 #pragma unroll
         for (int i = 0; i < NVG; ++i) {
             V16 val = rgv[i];
-            if (GQ) val = xform_bnbwd<T>(val, rgq[i], cgc + cl, cgc + 64 + cl, cgc + 128 + cl);
+            if (GQ) val = xform_bnbwd<T, TY>(val, rgq[i], cgc + cl, cgc + 64 + cl, cgc + 128 + cl);
             mask16(val, g_go[i] >= 0);
             const int v = tid + i * 256;
             *reinterpret_cast<V16*>(sG + (v / VPX) * k.psg + g_part * 16) = val;
@@ -569,7 +571,8 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(const WgK k) {
         for (int i = 0; i < NVH; ++i) {
             if (h_rc[i] < 0) continue;
             V16 val = rhv[i];
-            if (io.h.mode == STL_SRC_BN) val = xform_bn<T>(val, chc + cl, chc + 64 + cl, relu_lo);
+            if (io.h.mode == STL_SRC_BN) val = xform_bn<T, TY>(val, chc + cl, chc + 64 + cl, relu_lo);
+            else val = xform_cvt<T, TY>(val);
             mask16(val, h_go[i] >= 0);
             const int v = tid + i * 256;
             *reinterpret_cast<V16*>(sH + (v / VPX) * k.psh + g_part * 16) = val;
@@ -668,27 +671,28 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(const WgK k) {
     WSTAMP(8);
 }
 
-template <typename T, int KS, int NVH, bool GQ, int TPX>
+template <typename T, typename TY, int KS, int NVH, bool GQ, int TPX>
 int launch64(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad64_kernel<T, KS, NVH, GQ, TPX>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad64_kernel<T, KS, NVH, GQ, TPX, TY>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((wgrad64_kernel<T, KS, NVH, GQ, TPX>), grid, dim3(256), lds, st, k);
+    hipLaunchKernelGGL((wgrad64_kernel<T, KS, NVH, GQ, TPX, TY>), grid, dim3(256), lds, st, k);
     static char nbuf[160];
-    static const char* nm = stl_kname<T>(nbuf, "wgrad64_kernel", {KS, NVH, GQ, TPX});
+    static const char* nm = stl_kname<T>(nbuf, "wgrad64_kernel", {KS, NVH, GQ, TPX, stl_code<TY>()});
     stl_note_kernel(nm, true);
     STL_LAUNCH_CHECK("conv_wgrad64");
     return 0;
 }
 
 #if STL_DT != 0
+template <typename TY>
 int dispatch64(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {   // 1x1 layers, 128-pixel tiles
     const int nvh = ceil_div(k.HP * 8, 256);
     const bool gq = k.p.g.mode == STL_SRC_BNBWD;
-    if (k.p.TH * k.p.TW <= 128 && nvh <= 6) return gq ? launch64<__bf16, 1, 6, true, 128>(k, grid, lds, st) : launch64<__bf16, 1, 6, false, 128>(k, grid, lds, st);
+    if (k.p.TH * k.p.TW <= 128 && nvh <= 6) return gq ? launch64<__bf16, TY, 1, 6, true, 128>(k, grid, lds, st) : launch64<__bf16, TY, 1, 6, false, 128>(k, grid, lds, st);
     return stl_set_error("wgrad64: halo of %d pixels is too large for a %d-pixel tile", k.HP, k.p.TH * k.p.TW);
 }
 #endif
@@ -711,7 +715,7 @@ int wgrad_chunk(const stl_wgrad& p) {
     return (p.dtype == STL_BF16 && p.ks == 1 && p.stride == 1 && p.Co >= 64 && p.Ci >= 64) ? 64 : 32;
 }
 
-template <typename T, int KS>
+template <typename T, typename TY, int KS>
 int dispatch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
     {   // both 32-channel kernels address with 24-bit multiplies, scalar-unit division and 32-bit byte offsets
         const int64_t gpx = (int64_t)k.p.B * k.p.Ho * k.p.Wo, hpx = (int64_t)k.p.B * k.p.Hi * k.p.Wi;
@@ -727,16 +731,16 @@ int dispatch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
     STL_CHECK(k.p.TH * k.p.TW <= 128, "wgrad: tiles of more than 128 pixels are not supported");
     if constexpr (KS == 3) {   // 8 waves: quadrants x two tap groups, half the staging work per thread (bf16 and fp32)
         const int nvh8 = ceil_div(k.HP * vpx, 512);
-        if (nvh8 <= 2) return gq ? launch<T, KS, 2, true, 128, 8>(k, grid, lds, st) : launch<T, KS, 2, false, 128, 8>(k, grid, lds, st);
-        if (nvh8 <= 3) return gq ? launch<T, KS, 3, true, 128, 8>(k, grid, lds, st) : launch<T, KS, 3, false, 128, 8>(k, grid, lds, st);
-        if (nvh8 <= 5) return gq ? launch<T, KS, 5, true, 128, 8>(k, grid, lds, st) : launch<T, KS, 5, false, 128, 8>(k, grid, lds, st);
-        if (nvh8 <= 9) return gq ? launch<T, KS, 9, true, 128, 8>(k, grid, lds, st) : launch<T, KS, 9, false, 128, 8>(k, grid, lds, st);
+        if (nvh8 <= 2) return gq ? launch<T, TY, KS, 2, true, 128, 8>(k, grid, lds, st) : launch<T, TY, KS, 2, false, 128, 8>(k, grid, lds, st);
+        if (nvh8 <= 3) return gq ? launch<T, TY, KS, 3, true, 128, 8>(k, grid, lds, st) : launch<T, TY, KS, 3, false, 128, 8>(k, grid, lds, st);
+        if (nvh8 <= 5) return gq ? launch<T, TY, KS, 5, true, 128, 8>(k, grid, lds, st) : launch<T, TY, KS, 5, false, 128, 8>(k, grid, lds, st);
+        if (nvh8 <= 9) return gq ? launch<T, TY, KS, 9, true, 128, 8>(k, grid, lds, st) : launch<T, TY, KS, 9, false, 128, 8>(k, grid, lds, st);
         return stl_set_error("wgrad: halo of %d pixels is too large for the 3x3 kernel; shrink the tile", k.HP);
     }
-    if (nvh <= 3) return gq ? launch<T, KS, 3, true>(k, grid, lds, st) : launch<T, KS, 3, false>(k, grid, lds, st);
-    if (nvh <= 6) return gq ? launch<T, KS, 6, true>(k, grid, lds, st) : launch<T, KS, 6, false>(k, grid, lds, st);
-    if (nvh <= 9) return gq ? launch<T, KS, 9, true>(k, grid, lds, st) : launch<T, KS, 9, false>(k, grid, lds, st);
-    if (nvh <= 18) return gq ? launch<T, KS, 18, true>(k, grid, lds, st) : launch<T, KS, 18, false>(k, grid, lds, st);
+    if (nvh <= 3) return gq ? launch<T, TY, KS, 3, true>(k, grid, lds, st) : launch<T, TY, KS, 3, false>(k, grid, lds, st);
+    if (nvh <= 6) return gq ? launch<T, TY, KS, 6, true>(k, grid, lds, st) : launch<T, TY, KS, 6, false>(k, grid, lds, st);
+    if (nvh <= 9) return gq ? launch<T, TY, KS, 9, true>(k, grid, lds, st) : launch<T, TY, KS, 9, false>(k, grid, lds, st);
+    if (nvh <= 18) return gq ? launch<T, TY, KS, 18, true>(k, grid, lds, st) : launch<T, TY, KS, 18, false>(k, grid, lds, st);
     return stl_set_error("wgrad: halo of %d pixels needs %d staging vectors per thread (max 18); shrink the tile", k.HP, nvh);
 }
 
@@ -744,14 +748,18 @@ int dispatch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
 
 #if STL_DT != 0
 int stl_wgrad_backend_bf16(bool wide, const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
-    if (wide) return dispatch64(k, grid, lds, st);
-    return k.p.ks == 3 ? dispatch<__bf16, 3>(k, grid, lds, st) : dispatch<__bf16, 1>(k, grid, lds, st);
+    if (k.p.ydtype == STL_F16) {   // mixed mode: h and g.y are f16 forward tensors, dt and the MFMA operands bf16
+        if (wide) return dispatch64<f16>(k, grid, lds, st);
+        return k.p.ks == 3 ? dispatch<__bf16, f16, 3>(k, grid, lds, st) : dispatch<__bf16, f16, 1>(k, grid, lds, st);
+    }
+    if (wide) return dispatch64<__bf16>(k, grid, lds, st);
+    return k.p.ks == 3 ? dispatch<__bf16, __bf16, 3>(k, grid, lds, st) : dispatch<__bf16, __bf16, 1>(k, grid, lds, st);
 }
 #endif
 #if STL_DT != 1
 int stl_wgrad_backend_f32(bool wide, const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
     if (wide) return stl_set_error("wgrad: the 64 x 64-channel variant is bf16 only");
-    return k.p.ks == 3 ? dispatch<float, 3>(k, grid, lds, st) : dispatch<float, 1>(k, grid, lds, st);
+    return k.p.ks == 3 ? dispatch<float, float, 3>(k, grid, lds, st) : dispatch<float, float, 1>(k, grid, lds, st);
 }
 #endif
 
@@ -788,7 +796,9 @@ static int wgrad_run(const stl_wgrad* const* ps, int ng, void* stream) {
     const stl_wgrad& p = *ps[0];
   for (int i_ = 0; i_ < ng; ++i_) {
     const stl_wgrad& p = *ps[i_];
-    STL_CHECK(p.dtype == STL_F32 || p.dtype == STL_BF16, "wgrad: bad dtype");
+    STL_CHECK(p.dtype == STL_F32 || p.dtype == STL_BF16, "wgrad: bad dtype (gradients are fp32 or bf16)");
+    STL_CHECK(p.ydtype == 0 || p.ydtype == p.dtype || (p.dtype == STL_BF16 && p.ydtype == STL_F16), "wgrad: ydtype %d does not go with dtype %d", p.ydtype, p.dtype);
+    STL_CHECK(p.ydtype == ps[0]->ydtype, "wgrad_group: members differ in ydtype");
     STL_CHECK(p.ks == 1 || p.ks == 3, "wgrad: ks must be 1 or 3");
     STL_CHECK(p.stride == 1 || p.stride == 2, "wgrad: stride must be 1 or 2");
     const int kv = p.dtype == STL_BF16 ? 8 : 4;

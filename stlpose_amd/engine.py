@@ -32,7 +32,7 @@ MOMENTUM = 0.1   # reference HRnet.py:23 (fuse/transition BNs use the default, a
 
 
 def _esz(dtype: int) -> int:
-    return 2 if dtype == capi.BF16 else 4
+    return 4 if (dtype & 0xff) == capi.F32 else 2
 
 
 def choose_tile(B: int, Ho: int, Wo: int, stride: int, ks: int, esz: int, bn_cols: int = 64,
@@ -138,10 +138,17 @@ class Engine:
     def __init__(self, arch: Arch, store: ParamStore, B: int, H: int, W: int, dtype: int, training: bool):
         assert H % 32 == 0 and W % 32 == 0, "input H, W must be multiples of 32 (four stride-2 stages + 8x upsample)"
         self.arch, self.store, self.B, self.H, self.W = arch, store, B, H, W
-        self.dtype, self.training = dtype, training
+        # dtype: capi.F32, capi.BF16 or capi.MIXED (= dt2(BF16, F16)).  self.dtype = element type of the GRADIENT tensors (and, in
+        # the pure modes, of everything), self.fdtype = of the FORWARD tensors (raw conv outputs, sums, forward kernel-layout
+        # weights): f16 in the mixed mode -- BatchNorm bounds their range, and 10 mantissa bits instead of 7 cut the distance
+        # from the fp32 reference; gradients have no such bound and stay bf16.
+        self.dtype_code = dtype
+        self.dtype, self.fdtype = dtype & 0xff, ((dtype >> 8) & 0xff) or (dtype & 0xff)
+        self.ydtype = self.fdtype if self.fdtype != self.dtype else 0   # what the backward descriptors carry (0 = same)
+        self.training = training
         self.dev = store.device
         self.esz = _esz(dtype)
-        self.tdtype = torch.bfloat16 if dtype == capi.BF16 else torch.float32
+        self.tdtype = torch.float32 if self.dtype == capi.F32 else torch.bfloat16   # kernel-layout weights: just a byte container in the 16-bit modes
         self.lib = capi.lib()
         self.fwd_ops: List[Tuple] = []
         self.bwd_ops: List[Tuple] = []
@@ -241,7 +248,7 @@ class Engine:
         Ho, Wo = H // 2, W // 2
         t = self._act_tensor(B, Ho, Wo, 32)
         pd = capi.Patch()
-        pd.dtype, pd.B, pd.H, pd.W, pd.stride = self.dtype, B, H, W, 2
+        pd.dtype, pd.B, pd.H, pd.W, pd.stride = self.fdtype, B, H, W, 2
         pd.img, pd.out = self.img.data_ptr(), t.data_ptr()
         self.fwd_ops.append(("stl_patch3x3", pd, 0, [], [t.data_ptr()]))
         return Act("plain", t, B, Ho, Wo, 32, needs_grad=False)
@@ -266,7 +273,7 @@ class Engine:
         self.bns.append(bn)
         y = Act("bn", self._act_tensor(x.B, Ho, Wo, cout), x.B, Ho, Wo, cout, bn=bn, relu=relu)
         p = capi.Conv()
-        p.dtype = self.dtype
+        p.dtype = self.fdtype
         p.B, p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.Co = x.B, x.H, x.W, x.C, Ho, Wo, cout
         p.ks, p.stride, p.stuff = kks, kstride, 0
         p.TH, p.TW, p.shape = 0, 0, -1
@@ -306,7 +313,7 @@ class Engine:
         B, H, W, Cc = base.B, base.H, base.W, base.C
         z = Act("plain", self._act_tensor(B, H, W, Cc), B, H, W, Cc)
         p = capi.Fuse()
-        p.dtype, p.B, p.H, p.W, p.C, p.nterms, p.relu = self.dtype, B, H, W, Cc, len(terms), int(relu)
+        p.dtype, p.B, p.H, p.W, p.C, p.nterms, p.relu = self.fdtype, B, H, W, Cc, len(terms), int(relu)
         for i, (a, s, tr) in enumerate(terms):
             assert a.C == Cc and a.H << s == H and a.W << s == W, "fuse: term shape mismatch"
             p.t[i].src = self._src(a, relu=tr)
@@ -329,7 +336,7 @@ class Engine:
         self.head_w = st.master.data_ptr() + 4 * st.param_off[key + ".weight"]
         self.head_b = st.master.data_ptr() + 4 * st.param_off[key + ".bias"]
         hd = capi.Head()
-        hd.dtype, hd.B, hd.H, hd.W, hd.Ci, hd.J = self.dtype, x.B, x.H, x.W, x.C, joints
+        hd.dtype, hd.B, hd.H, hd.W, hd.Ci, hd.J = self.fdtype, x.B, x.H, x.W, x.C, joints
         hd.x, hd.w, hd.bias, hd.out = x.ptr, self.head_w, self.head_b, self.out.data_ptr()
         self.fwd_ops.append(("stl_head_forward", hd, 0, [x.ptr], [self.out.data_ptr()]))
         x.consumers += 1
@@ -432,7 +439,7 @@ class Engine:
                 part_off = self._slab_elems
                 self._slab_elems += (nblk * nel + 3) // 4 * 4   # keep every entry 16-byte aligned
                 hb = capi.HeadBwd()
-                hb.dtype, hb.B, hb.H, hb.W, hb.Ci, hb.J, hb.nblk = self.dtype, x.B, x.H, x.W, x.C, joints, nblk
+                hb.dtype, hb.B, hb.H, hb.W, hb.Ci, hb.J, hb.nblk = capi.dt2(self.dtype, self.fdtype), x.B, x.H, x.W, x.C, joints, nblk
                 hb.x, hb.w, hb.dout, hb.dx = x.ptr, self.head_w, self.dout.data_ptr(), dx.data_ptr()
                 self._head_bwd_args = (hb, part_off)
                 ops.append(("stl_head_backward", hb, 0, [self.dout.data_ptr(), x.ptr], [dx.data_ptr(), id(hb)]))
@@ -456,6 +463,7 @@ class Engine:
                 assert 1 <= len(z.grads) <= 4, f"fuse output has {len(z.grads)} gradient contributions"
                 p = capi.FuseBwd()
                 p.dtype, p.B, p.H, p.W, p.C = self.dtype, z.B, z.H, z.W, z.C
+                p.ydtype = self.ydtype
                 p.ngrads, p.relu = len(z.grads), int(relu)
                 for i, gt in enumerate(z.grads):
                     p.dz[i] = gt.data_ptr()
@@ -480,6 +488,7 @@ class Engine:
                     else:
                         u = capi.UpBwd()
                         u.dtype, u.B, u.H, u.W, u.C, u.shift = self.dtype, a.B, a.H, a.W, a.C, s
+                        u.ydtype = self.ydtype
                         u.du = du.data_ptr()
                         a.dt = self._new_grad(a)
                         u.dt = a.dt.data_ptr()
@@ -498,7 +507,7 @@ class Engine:
                 if not x.needs_grad:
                     continue
                 d = capi.Conv()
-                d.dtype = self.dtype
+                d.dtype, d.ydtype = self.dtype, self.ydtype
                 d.B, d.Hi, d.Wi, d.Ci = y.B, y.H, y.W, y.C
                 d.Ho, d.Wo, d.Co = x.H, x.W, x.C
                 d.ks, d.stride, d.stuff = kks, 1, int(kstride == 2)
@@ -637,7 +646,7 @@ class Engine:
         """Weight-gradient launch of one convolution (split-K slabs): off the critical path (only the data-gradient chain
         is on it); _balance_streams places it on an idle queue where there is one."""
         wg = capi.Wgrad()
-        wg.dtype = self.dtype
+        wg.dtype, wg.ydtype = self.dtype, self.ydtype
         wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = x.B, x.H, x.W, x.C, y.H, y.W, y.C
         wg.ks, wg.stride = kks, kstride
         ctile = capi.lib().stl_wgrad_chunk(C.byref(wg))   # 32, or 64 for the wide-channel variant (1x1 layers)
@@ -791,7 +800,7 @@ class Engine:
 
     def prep_weights(self, stream: int):
         st = self.store
-        capi.call("stl_weight_prep", self.dtype, st.master.data_ptr(), self.wk.data_ptr(), self._wprep_tab.data_ptr(),
+        capi.call("stl_weight_prep", capi.dt2(self.dtype, self.fdtype), st.master.data_ptr(), self.wk.data_ptr(), self._wprep_tab.data_ptr(),
                   self._wprep_n, self._wprep_blocks, stream)
 
     def prep_weights_range(self, i: int, stream: int):
@@ -805,7 +814,7 @@ class Engine:
         i0, i1 = b["conv0"], b["conv1"]
         if i1 > i0:
             st = self.store
-            capi.call("stl_weight_prep_range", self.dtype, st.master.data_ptr(), self.wk.data_ptr(),
+            capi.call("stl_weight_prep_range", capi.dt2(self.dtype, self.fdtype), st.master.data_ptr(), self.wk.data_ptr(),
                       self._wprep_tab.data_ptr() + i0 * C.sizeof(capi.WPrep), i1 - i0, self._wprep_blk0[i0],
                       self._wprep_blk0[i1] - self._wprep_blk0[i0], stream)
 
@@ -857,7 +866,7 @@ class Engine:
             i0, i1 = b["conv0"], b["conv1"]
             if i1 > i0:
                 w = capi.WPrepRange()
-                w.dtype, w.n, w.blk_base, w.nblocks = self.dtype, i1 - i0, self._wprep_blk0[i0], self._wprep_blk0[i1] - self._wprep_blk0[i0]
+                w.dtype, w.n, w.blk_base, w.nblocks = capi.dt2(self.dtype, self.fdtype), i1 - i0, self._wprep_blk0[i0], self._wprep_blk0[i1] - self._wprep_blk0[i0]
                 w.master, w.wk, w.tab = self.store.master.data_ptr(), self.wk.data_ptr(), self._wprep_tab.data_ptr() + i0 * C.sizeof(capi.WPrep)
                 new_ops.append(("stl_wprep_range", w, strm, [("optim", i)], [("wprep", i)]))
                 self._optim_descs.append(w)

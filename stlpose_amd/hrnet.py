@@ -43,7 +43,9 @@ def _dtype_code(name: str) -> int:
         return capi.BF16
     if name in ("fp32", "f32", "float32"):
         return capi.F32
-    raise ValueError(f"compute_dtype must be 'bf16' or 'fp32', got {name!r}")
+    if name in ("mixed", "f16bf16", "fp16bf16"):   # forward tensors f16, gradients bf16 (capi.MIXED)
+        return capi.MIXED
+    raise ValueError(f"compute_dtype must be 'mixed', 'bf16' or 'fp32', got {name!r}")
 
 
 def norm_device(device) -> torch.device:

@@ -23,8 +23,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import hrnet_ref, pose_ref  # noqa: E402
 
 
+RT = torch.bfloat16   # rounding type of the emulation (switched to torch.float16 for the mixed mode's forward tensors)
+
+
 def r16(t):
-    return t.to(torch.bfloat16).to(t.dtype)
+    return t.to(RT).to(t.dtype)
 
 
 class Rounding:
@@ -98,6 +101,12 @@ def main():
         out_hip = m(ti).cpu().numpy()
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     del ts, m
+    mm_ = PoseHighResolutionNet("w32", "mixed")
+    mm_.load_state_dict(sd, strict=True)
+    mm_ = mm_.cuda().train()
+    with torch.no_grad():
+        out_mixed = mm_(ti).cpu().numpy()
+    del mm_
     ref = hrnet_ref.RefPoseNet("w32")
     ref.load_state_dict(sd, strict=True)
     ref.train()
@@ -131,6 +140,12 @@ def main():
               f"moved>1px {int((disp > 1).sum())}  PCK {pose_ref.pck_accuracy(o, tgt)[1]:.4f}", flush=True)
     print(f"oracle fp32 PCK {pose_ref.pck_accuracy(base, tgt)[1]:.4f}")
     report("HIP bf16 path", out_hip)
+    report("HIP mixed path (f16 fwd)", out_mixed)
+    global RT
+    RT = torch.float16
+    with torch.no_grad(), Rounding(ref, "wxys", None):
+        report("f16 emulation w+x+y+s", ref(x).numpy())
+    RT = torch.bfloat16
     for tag, what, centre in (("w only", "w", None), ("x only", "x", None), ("y only", "y", None), ("s only", "s", None),
                               ("w+x+y+s (= bf16_storage)", "wxys", None), ("w+x+s, y centred(batch)", "wxs", "batch"),
                               ("w+x+s, y centred(running)", "wxs", "running"), ("y centred(batch) only", "", "batch"), ("w+x+s, y exact", "wxs", None),
