@@ -23,7 +23,8 @@ sys.path.insert(0, ROOT)
 
 FLOPS_PER_IMG = {("w32", 384, 288): 103.11e9, ("w32", 256, 192): 45.83e9, ("w48", 384, 288): 211.74e9,
                  ("w48", 256, 192): 94.11e9}  # fwd + dgrad + wgrad, convs only
-MFMA_PEAK_BF16 = 2500.0  # TFLOP/s dense (MI355X_MICROARCH.md)
+MFMA_PEAK_BF16 = 2500.0  # TFLOP/s dense (MI355X_MICROARCH.md; the f16 MFMA forms take the same cycles)
+DTYPE_LABEL = {"mixed": "f16/bf16", "bf16": "bf16", "fp32": "f32"}   # mixed: forward tensors + forward MFMA operands f16, gradients bf16, fp32 accumulate
 HBM_PEAK = 8000.0        # GB/s
 
 
@@ -40,54 +41,97 @@ def synth_batch(B, H, W, rank, device, sigma=3.0, joints=17):
     return img.to(device), tgt.to(device), tw.to(device)
 
 
-def time_dominant_kernel(ts):
-    """The dominant kernel by GPU time is the 3x3 stride-1 weight gradient `wgrad_kernel<bf16,KS=3,GQ=1>` (BatchNorm
-    backward applied on load; `wgrad_ws_kernel` with STL_WGRAD_WS=1).  Since round 3 most of its launches are GROUPED (stl_conv_wgrad_group: up to four
-    weight gradients of one branch per launch).  Every launch of that instantiation in one backward pass -- grouped
-    or single -- is timed on its own with HIP events on the launch stream; achieved = algorithmic FLOPs (bytes) of all
-    members / sum of durations; the per-launch figures are averages over those launches."""
+def time_kernel_families(ts):
+    """Which kernel is the dominant one is MEASURED, not assumed: every launch of one forward + backward pass is replayed alone
+    (a one-op native program on the launch stream, HIP events around it) and the durations are summed per kernel INSTANTIATION
+    -- the name the library reports for the launch it just made (stl_last_kernel: template arguments in declaration order,
+    what rocprofv3's kernel trace shows after demangling; tools/kernel_names.py maps one onto the other).  Per family:
+    launches, summed time, algorithmic FLOPs and bytes (every tensor a launch reads or writes once, split-K
+    slabs and halo re-reads are NOT algorithmic)."""
     from stlpose_amd import capi
-    eng = ts.eng
-
-    def dominant(d):
-        return d.ks == 3 and d.stride == 1 and d.g.mode == capi.SRC_BNBWD
-    launches = []   # (callable, member descriptors)
-    lib = capi.lib()
-    for n, d, *_ in eng.bwd_ops:
-        if n == "stl_conv_wgrad" and dominant(d):
-            launches.append((lambda st, d=d: lib.stl_conv_wgrad(C.byref(d), st), [d]))
-        elif n == "stl_conv_wgrad_group" and dominant(d.members[0]):
-            launches.append((lambda st, d=d: lib.stl_conv_wgrad_group(C.byref(d), st), list(d.members)))
-    if not launches:
-        return None
+    eng, lib = ts.eng, capi.lib()
     st = torch.cuda.current_stream().cuda_stream
-    for fn, _ in launches[:8]:
-        fn(st)
+    esz = eng.esz
+    streams = (C.c_void_p * 1)(st)
+
+    def cost(name, d):
+        if name == "stl_conv_forward":
+            px = d.B * (d.Hi * d.Wi if d.stuff else d.Ho * d.Wo)
+            fl = 2.0 * px * d.Co * d.Ci * d.ks * d.ks
+            by = esz * (d.B * d.Hi * d.Wi * d.Ci * (2 if d.src.mode in (capi.SRC_BNBWD, capi.SRC_BNADD) else 1)
+                        + d.B * d.Ho * d.Wo * d.Co * (1 + bool(d.mask_y) + bool(d.addend) + bool(d.mask_z)) + d.B * d.Hi * d.Wi * d.Ci * bool(d.src_out))
+            return fl, by
+        if name in ("stl_conv_wgrad", "stl_conv_wgrad_group"):
+            ms_ = d.members if name == "stl_conv_wgrad_group" else [d]
+            fl = sum(2.0 * m.B * m.Ho * m.Wo * m.Co * m.Ci * m.ks * m.ks for m in ms_)
+            by = sum(esz * (m.B * m.Hi * m.Wi * m.Ci + m.B * m.Ho * m.Wo * m.Co * (2 if m.g.mode == capi.SRC_BNBWD else 1)) + m.Co * m.Ci * m.ks * m.ks * 4 for m in ms_)
+            return fl, by
+        if name == "stl_fuse_forward":
+            return 0.0, esz * d.B * d.H * d.W * d.C * (1 + sum(1.0 / (1 << (2 * d.t[i].shift)) for i in range(d.nterms)))
+        if name == "stl_fuse_backward":
+            return 0.0, esz * d.B * d.H * d.W * d.C * (d.ngrads + 1 + bool(d.relu) + d.nbn)
+        if name == "stl_upsample_backward":
+            return 0.0, esz * d.B * d.H * d.W * d.C * ((1 << (2 * d.shift)) + 2)
+        return 0.0, 0.0
+    fams, progs = {}, []
+    for ops in (eng.fwd_ops, eng.bwd_ops):
+        for name, d, *_ in ops:
+            arr = (capi.Op * 1)()
+            arr[0].kind, arr[0].stream, arr[0].desc, arr[0].nwait, arr[0].record = capi.OP_KIND[name], 0, C.addressof(d), 0, 0
+            h = C.c_void_p()
+            capi.call("stl_program_create", arr, 1, 1, C.byref(h))
+            progs.append((h, arr, name, d))
+    for h, *_ in progs[:16]:
+        lib.stl_program_run(h, streams)
     torch.cuda.synchronize()
     evs = []
-    for fn, members in launches:
+    for h, _arr, name, d in progs:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        fn(st)
+        rc = lib.stl_program_run(h, streams)
         e1.record()
-        evs.append((e0, e1, members))
+        assert rc == 0, lib.stl_last_error().decode()
+        evs.append((e0, e1, lib.stl_last_kernel().decode(), name, d))
     torch.cuda.synchronize()
-    tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
-    esz = 4 if eng.dtype == capi.F32 else 2
-    flops = sum(2.0 * d.B * d.Ho * d.Wo * d.Co * d.Ci * 9 for _, _, ms in evs for d in ms)
-    # SURVEY 8(d): h, dt and y read once, dw written once (split-K slabs are NOT algorithmic bytes)
-    bytes_alg = sum((d.B * d.Hi * d.Wi * d.Ci + 2 * d.B * d.Ho * d.Wo * d.Co) * esz + d.Co * d.Ci * 9 * 4 for _, _, ms in evs for d in ms)
-    nconv = sum(len(ms) for _, _, ms in evs)
-    return dict(kernel="wgrad_kernel<bf16,KS=3,GQ=1> (3x3 stride-1 weight gradient, BN-backward on load; grouped launches of up to "
-                       f"{max(len(ms) for _, _, ms in evs)} layers of one branch)",
-                launches=len(evs), convs=nconv, ms=tot_ms / len(evs), tflops=flops / tot_ms / 1e9, gbs=bytes_alg / tot_ms / 1e6)
+    for e0, e1, kern, name, d in evs:
+        f = fams.setdefault(kern, dict(kernel=kern, launches=0, layers=0, ms=0.0, flops=0.0, bytes=0.0, replay=[]))
+        fl, by = cost(name, d)
+        f["launches"] += 1
+        f["layers"] += d.n if name == "stl_conv_wgrad_group" else 1
+        f["ms"] += e0.elapsed_time(e1)
+        f["flops"] += fl
+        f["bytes"] += by
+    for (h, _arr, name, d), (_e0, _e1, kern, *_r) in zip(progs, evs):
+        fams[kern]["replay"].append(h)
+    return sorted(fams.values(), key=lambda f: -f["ms"]), progs
 
 
-def cpu_baseline(arch, H, W, batch=32, steps=3, adam=True):
+def family_roofline(f):
+    """Roofline entry of one kernel family: bound = the roofline that takes longer at peak for the family's algorithmic work."""
+    t_mfma, t_hbm = f["flops"] / (MFMA_PEAK_BF16 * 1e12), f["bytes"] / (HBM_PEAK * 1e9)
+    sec = f["ms"] * 1e-3
+    tf, gbs = f["flops"] / sec / 1e12, f["bytes"] / sec / 1e9
+    out = dict(kernel=f["kernel"], launches_per_step=f["launches"], layers_per_step=f["layers"], sum_ms_per_step=round(f["ms"], 3),
+               avg_launch_us=round(f["ms"] / f["launches"] * 1e3, 2), algorithmic_TFLOPs=round(tf, 2), mfma_frac=round(tf / MFMA_PEAK_BF16, 4),
+               algorithmic_GBps=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK, 4), algorithmic_bytes_per_launch=round(f["bytes"] / f["launches"]),
+               algorithmic_flops_per_launch=round(f["flops"] / f["launches"]))
+    if t_mfma >= t_hbm:
+        out.update(bound="mfma", achieved=round(tf, 2), peak=MFMA_PEAK_BF16, unit="TFLOP/s", frac=round(tf / MFMA_PEAK_BF16, 4))
+    else:
+        out.update(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK, unit="GB/s", frac=round(gbs / HBM_PEAK, 4))
+    return out
+
+
+def csrc_hash():
+    from stlpose_amd import build
+    return build.source_id()
+
+
+def cpu_baseline(arch, H, W, batch=32, steps=6, adam=True):
     """The oracle (plain torch fp32 restatement of the reference graph) timed on the host cores at the benchmarked
     batch size (bs 32 forward + MSE + backward for a like-for-like ratio; the Adam step is in the timed
-    region like in the GPU line).  Bounded sample: `steps` steps (~7 s each at W32 384x288 on 16 threads), median of
-    all but the first."""
+    region like in the GPU line).  Bounded sample: `steps` steps (~4-7 s each at W32 384x288 on 16 threads: one warm-up +
+    five timed by default), median of all but the first."""
     from oracle import hrnet_ref, pose_ref
     torch.manual_seed(0)
     torch.set_num_threads(min(16, os.cpu_count() or 1))  # the GPU box's CPU share for one GPU
@@ -167,13 +211,13 @@ def extra_fp32_path(arch, batch, H, W, dev, steps=6, warmup=2):
                               note="whole step against the fp32-input MFMA peak (v_mfma_f32_16x16x4_f32)"))
 
 
-def extra_train_leg(arch, batch, H, W, dev, steps=20, warmup=6, cpu_batch=8):
+def extra_train_leg(arch, batch, H, W, dev, steps=20, warmup=6, cpu_batch=8, dtype="mixed"):
     """The same train step (bf16, fwd + MSE + bwd + Adam) at another configuration of BASELINE.json's list: W32 256x192
     (north_star: "throughput on synthetic 256x192 and 384x288 batches") and W48 384x288 (configs[2]'s shape on one GPU)."""
     from stlpose_amd import PoseHighResolutionNet
     from stlpose_amd.train_step import TrainStep
     torch.manual_seed(0)
-    model = PoseHighResolutionNet(arch, "bf16").to(dev)
+    model = PoseHighResolutionNet(arch, dtype).to(dev)
     ts = TrainStep(model, batch, H, W, optimizer="adam", lr=1e-3, device=dev)
     ts.load_batch(*synth_batch(batch, H, W, 0, dev, sigma=3.0 if H >= 384 else 2.0))
     for _ in range(warmup):
@@ -190,7 +234,7 @@ def extra_train_leg(arch, batch, H, W, dev, steps=20, warmup=6, cpu_batch=8):
     del ts, model
     torch.cuda.empty_cache()
     out = dict(metric=f"images/sec/GPU HRNet-{arch.upper()} {H}x{W} bs={batch} train step (fwd+MSE+bwd+Adam)", value=round(batch / dt, 2),
-               unit="images/sec", ms_per_step=round(dt * 1e3, 3), dtype="bf16", steps=steps, warmup=warmup, loss=loss,
+               unit="images/sec", ms_per_step=round(dt * 1e3, 3), dtype=DTYPE_LABEL[dtype], steps=steps, warmup=warmup, loss=loss,
                roofline=dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_PEAK_BF16, unit="TFLOP/s", frac=round(tf / MFMA_PEAK_BF16, 4),
                              traffic=None, note="whole step: algorithmic conv FLOPs (SURVEY 8(d)) / step time"))
     if cpu_batch:
@@ -206,7 +250,7 @@ def extra_eval_path(dev, batches=10, batch=32, H=384, W=288, persons_per_image=4
     from stlpose_amd import PoseHighResolutionNet
     from stlpose_amd.evaluate import Evaluator
     torch.manual_seed(0)
-    model = PoseHighResolutionNet("w32", "bf16").to(dev).eval()
+    model = PoseHighResolutionNet("w32", "mixed").to(dev).eval()   # eval: forward only, i.e. all-f16 tensors
     img, tgt, tw = synth_batch(batch, H, W, 0, dev, sigma=3.0)
     rng = np.random.Generator(np.random.PCG64(5))
 
@@ -226,7 +270,7 @@ def extra_eval_path(dev, batches=10, batch=32, H=384, W=288, persons_per_image=4
     n = batches * batch
     tf = n / dt * 2 * 34.403e9 / 1e12     # two forward passes per image (F_fwd 34.403 GFLOP at 384x288)
     out = dict(metric="images/sec evaluation path HRNet-W32 384x288 bs=32: flip-test forward x2 + flip_merge + loss + PCK + final_preds + rescoring / OKS-NMS",
-               value=round(n / dt, 2), unit="images/sec", ms_per_batch=round(dt / batches * 1e3, 3), dtype="bf16", batches=batches,
+               value=round(n / dt, 2), unit="images/sec", ms_per_batch=round(dt / batches * 1e3, 3), dtype="f16", batches=batches,
                results=len(res.get("results", [])) if isinstance(res, dict) else None,
                roofline=dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_PEAK_BF16, unit="TFLOP/s", frac=round(tf / MFMA_PEAK_BF16, 4), traffic=None,
                              note="2 x forward conv FLOPs per image / wall time, host post-processing included"))
@@ -284,13 +328,14 @@ def extra_vgg_cfg4(dev, reps=5):
     # CPU baseline: the oracle on 2 pairs (bounded sample of the same workload); the only use of oracle/ in this leg
     from oracle import vgg_ref
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    t0 = time.time()
     with torch.no_grad():
+        vgg_ref.vgg_perceptual_loss(a[:1], b[:1], w, resize=False)   # warm-up (thread pool, allocator)
+        t0 = time.time()
         vgg_ref.vgg_perceptual_loss(a[:2], b[:2], w, resize=False)
     cpu = 2 / (time.time() - t0)
     return dict(metric="image pairs/sec VGG16 perceptual loss forward 512x512 bs=16 (V1 of cfg4)", unit="pairs/sec", **res,
                 cpu_baseline=dict(value=round(cpu, 3), unit="pairs/sec", cores=torch.get_num_threads(), kind="port",
-                                  sample="oracle.vgg_ref fp32, 2 pairs of 3x512x512, resize=False, one evaluation"))
+                                  sample="oracle.vgg_ref fp32, 2 pairs of 3x512x512, resize=False, one evaluation after one warm-up pair"))
 
 
 def extra_vgg19_style(dev, reps=3):
@@ -320,12 +365,13 @@ def extra_vgg19_style(dev, reps=3):
         torch.cuda.empty_cache()
     from oracle import vgg_ref   # CPU baseline only
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    t0 = time.time()
     with torch.no_grad():
+        vgg_ref.vgg19_style_content_loss(x[:1, :, :128, :128], c[:1, :, :128, :128], s_[:1, :, :128, :128], w)   # warm-up on a crop
+        t0 = time.time()
         vgg_ref.vgg19_style_content_loss(x[:1], c[:1], s_[:1], w)
     return dict(metric="image triplets/sec VGG19 content + Gram style loss forward 512x512 bs=16 (cfg4; V2, parity unpinned)", unit="triplets/sec", **res,
                 cpu_baseline=dict(value=round(1 / (time.time() - t0), 3), unit="triplets/sec", cores=torch.get_num_threads(), kind="port",
-                                  sample="oracle.vgg_ref.vgg19_style_content_loss fp32, 1 triplet of 3x512x512, one evaluation"))
+                                  sample="oracle.vgg_ref.vgg19_style_content_loss fp32, 1 triplet of 3x512x512, one evaluation after a warm-up crop"))
 
 
 def main():
@@ -337,7 +383,7 @@ def main():
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=288)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
-    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--dtype", default="mixed", help="mixed (forward tensors f16, gradients bf16: the default 16-bit mode), bf16 or fp32")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32-path and VGG cfg4 legs")
@@ -467,38 +513,43 @@ def main():
 
     if rank == 0:
         flops_img = FLOPS_PER_IMG.get((a.arch, a.height, a.width))
-        dom = time_dominant_kernel(ts)
-        roof = None
-        if dom:
-            # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
-            # (tools/pmc_traffic.py -> profiles/r*_pmc_wgrad.json); null if they describe another config
+        fams, progs = time_kernel_families(ts)
+        roof = others = None
+        if fams:
+            roof = family_roofline(fams[0])
+            # HBM bytes per launch of THAT kernel from the committed rocprofv3 --pmc passes of this same command
+            # (tools/pmc_traffic.py -> profiles/r*_pmc_dominant.json); used only if it was taken on these kernel sources
+            # (build id) for this kernel and launch count, else null
             traffic = traffic_src = None
             import glob
-            for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_wgrad.json"))):
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dominant.json"))):
                 try:
                     rec = json.load(open(f))
-                    if rec.get("launches") == dom["launches"] and (a.arch, a.height, a.width, a.batch, a.dtype) == ("w32", 384, 288, 32, "bf16") \
-                            and rec.get("wgrad_group", "1") == os.environ.get("STLPOSE_WGRAD_GROUP", "4"):
+                    if rec.get("kernel") == roof["kernel"] and rec.get("launches") == roof["launches_per_step"] and rec.get("build_id") == csrc_hash() \
+                            and (a.arch, a.height, a.width, a.batch, a.dtype) == ("w32", 384, 288, 32, rec.get("dtype", "mixed")):
                         traffic, traffic_src = round(rec["traffic_bytes_per_launch"]), "profiles/" + os.path.basename(f)
                 except Exception:
                     pass
-            roof = dict(bound="mfma", achieved=round(dom["tflops"], 2), peak=MFMA_PEAK_BF16, unit="TFLOP/s",
-                        frac=round(dom["tflops"] / MFMA_PEAK_BF16, 4), traffic=traffic, kernel=dom["kernel"],
-                        launches_per_step=dom["launches"], layers_per_step=dom["convs"], avg_launch_us=round(dom["ms"] * 1e3, 2),
-                        algorithmic_GBps=round(dom["gbs"], 1), hbm_frac=round(dom["gbs"] / HBM_PEAK, 4),
-                        algorithmic_bytes_per_launch=round(dom["gbs"] * dom["ms"] * 1e6),
-                        traffic_unit="HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)",
-                        traffic_source=(traffic_src + " (rocprofv3 --pmc passes of this command, committed; not measured in this run)") if traffic_src else None)
+            roof.update(traffic=traffic, traffic_unit="HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)",
+                        traffic_source=(traffic_src + " (rocprofv3 --pmc passes of this command on this build id, committed; not measured in this run)") if traffic_src else None,
+                        chosen_by="largest summed duration over one forward + backward pass, every launch timed alone with HIP events in this run")
+            others = [family_roofline(f) for f in fams[1:6]]
+            # the dominant family's launches once more, back to back, as the LAST dispatches of the process: what tools/pmc_traffic.py reads
+            lib_ = __import__("stlpose_amd.capi", fromlist=["lib"]).lib()
+            streams_ = (C.c_void_p * 1)(torch.cuda.current_stream().cuda_stream)
+            for h in fams[0]["replay"]:
+                lib_.stl_program_run(h, streams_)
+            torch.cuda.synchronize()
         out = dict(metric=f"images/sec/GPU HRNet-{a.arch.upper()} {a.height}x{a.width} train step; PCKh@0.5 parity", value=round(value, 2),
                    unit="images/sec", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3),
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.dtype, data="synthetic",
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype=DTYPE_LABEL.get(a.dtype, a.dtype), data="synthetic",
                    config=dict(workload=f"HRNet-{a.arch.upper()} {a.height}x{a.width} bs={a.batch}/GPU train step "
                                         f"(fwd+MSE+bwd+Adam{'+RCCL allreduce' if world > 1 else ''}), random-init weights",
                                global_batch=a.batch * world, parallelism=f"dp{world}"),
                    loss=loss,
                    step_tflops=round(value * flops_img / 1e12, 2) if flops_img else None,
                    step_mfma_frac=round(value / world * flops_img / 1e12 / MFMA_PEAK_BF16, 4) if flops_img else None,
-                   roofline=roof)
+                   roofline=roof, roofline_next=others)
         if comm is not None:
             out["comm"] = comm
         if world == 1 and not a.no_extras:
@@ -507,6 +558,7 @@ def main():
             extras = {}
             for name, fn in (("w32_256x192", lambda: extra_train_leg("w32", a.batch, 256, 192, dev)),
                              ("w48_384x288", lambda: extra_train_leg("w48", a.batch, 384, 288, dev, steps=12, warmup=4)),
+                             ("pure_bf16", lambda: extra_train_leg(a.arch, a.batch, a.height, a.width, dev, steps=12, warmup=4, cpu_batch=0, dtype="bf16")),
                              ("eval_path", lambda: extra_eval_path(dev)),
                              ("fp32_path", lambda: extra_fp32_path(a.arch, a.batch, a.height, a.width, dev)),
                              ("vgg_cfg4", lambda: extra_vgg_cfg4(dev)), ("vgg19_style_cfg4", lambda: extra_vgg19_style(dev))):

@@ -90,7 +90,7 @@ class PoseHighResolutionNet(nn.Module):
     def __init__(self, arch: str = "w32", compute_dtype: Optional[str] = None, **kwargs):
         super().__init__()
         self.arch: Arch = ARCHS[arch] if isinstance(arch, str) else arch
-        self.compute_dtype = _dtype_code(compute_dtype or os.environ.get("STLPOSE_DTYPE", "bf16"))
+        self.compute_dtype = _dtype_code(compute_dtype or os.environ.get("STLPOSE_DTYPE", "mixed"))
         self._reg = registry(self.arch)
         self._store: Optional[ParamStore] = None
         self._engines: Dict[Tuple, Engine] = {}

@@ -68,7 +68,7 @@ def update_train_logs(exp_path: str, logs: dict, iterations: int, train_loss, va
 
 class Trainer:
     def __init__(self, exp_path: str, exp_data: dict, train_loader: Iterable, valid_loader: Iterable, batch_size: int,
-                 arch: str = "w32", compute_dtype: str = "bf16", checkpoint: Optional[str] = None,
+                 arch: str = "w32", compute_dtype: str = "mixed", checkpoint: Optional[str] = None,
                  resume_training: bool = False, process_group=None, device="cuda", acc_every: int = 1):
         self.exp_path, self.exp_data = exp_path, exp_data
         self.train_loader, self.valid_loader = train_loader, valid_loader

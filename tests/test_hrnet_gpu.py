@@ -152,6 +152,62 @@ def test_w32_bf16_close_to_fp32_reference(golden_dir):
     np.testing.assert_allclose(vals, g["gradnorm_vals"], rtol=0.1)
 
 
+@pytest.mark.parametrize("tag,hw,sigma", [("256x192", (256, 192), 2.0), ("384x288", (384, 288), 3.0)])
+def test_w32_mixed_vs_reference_golden(golden_dir, tag, hw, sigma):
+    """The mixed 16-bit mode (forward tensors f16, gradients bf16) against the REFERENCE's fixture with ABSOLUTE
+    bars: train-mode forward + MSE + backward at BASELINE configs[0]/[1] shapes (bs 2).  Measured on MI355X: output 4.5e-3 /
+    5.8e-3 of |out|max (the pure-bf16 path: 4.0e-2 / 4.3e-2), loss 1.5e-5 / 2.7e-5 relative."""
+    g = np.load(os.path.join(golden_dir, f"g3_w32_{tag}.npz"))
+    img, tgt, tw = synth_batch(2, hw[0], hw[1], seed=1234, sigma=sigma)
+    m = _load_synth(PoseHighResolutionNet("w32", "mixed")).cuda().train()
+    out = m(torch.from_numpy(img).cuda())
+    loss = PersonMSELoss()(out, torch.from_numpy(tgt).cuda(), torch.from_numpy(tw).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    o = out.detach().cpu().numpy()
+    err = np.abs(o.reshape(-1)[::64] - g["out_sample"]).max() / float(g["out_absmax"])
+    p, _ = get_max_preds_hrnet(o)
+    agree = float((p == g["argmax_xy"]).all(-1).mean())
+    gn = {}
+    for k, prm in m.named_parameters():
+        assert not torch.isnan(prm.grad).any(), k
+        top = k.split(".")[0]
+        gn[top] = gn.get(top, 0.0) + float((prm.grad.double() ** 2).sum())
+    vals = np.array([np.sqrt(gn[k]) for k in g["gradnorm_keys"]])
+    _diag(f"diag_w32_mixed_{tag}.txt", [f"out rel err {err:.3e}", f"argmax agreement {agree:.3f}", f"loss {loss.item()} ref {float(g['loss'])}",
+                                        "gradnorm " + " ".join(f"{k}:{v:.4e}/{r:.4e}" for k, v, r in zip(g["gradnorm_keys"], vals, g["gradnorm_vals"]))])
+    assert err < 1.2e-2, f"mixed-mode output error {err:.3e}"
+    assert agree >= 0.85, f"argmax agreement {agree:.3f} (random-weight heat maps have near-ties)"
+    assert abs(loss.item() - float(g["loss"])) < 2e-4 * float(g["loss"])
+    np.testing.assert_allclose(vals, g["gradnorm_vals"], rtol=5e-2)   # gradients are bf16 like in the pure mode
+    np.testing.assert_allclose(m.bn1.running_mean.cpu().numpy(), g["rm_bn1"], rtol=2e-3, atol=1e-4)
+
+
+def test_tiny_mixed_full_gradients_vs_reference_golden(golden_dir):
+    """Every full gradient the tiny fixture holds, through the mixed mode: exercises every backward kernel's second element type
+    (BatchNorm-backward source y, mask_y, mask_z, the weight gradient's h, the sums' z, the head's x are f16; dt, du, dx bf16)."""
+    g = np.load(os.path.join(golden_dir, "g1_tiny_train.npz"))
+    m = _load_synth(PoseHighResolutionNet("tiny", "mixed")).cuda().train()
+    out = m(torch.from_numpy(g["img"]).cuda())
+    loss = PersonMSELoss()(out, torch.from_numpy(g["target"]).cuda(), torch.from_numpy(g["target_weight"]).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    err = np.abs(out.detach().cpu().numpy() - g["output"]).max() / np.abs(g["output"]).max()
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    worst = []
+    for k in g.files:
+        if k.startswith("grad/"):
+            ref = g[k]
+            got = grads[k[5:]].cpu().numpy()
+            den = max(np.abs(ref).max(), 1e-12)
+            cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
+            worst.append((np.abs(got - ref).max() / den, cos, k))
+    worst.sort(reverse=True)
+    _diag("diag_tiny_mixed.txt", [f"out rel err {err:.3e} loss {loss.item()} ref {float(g['loss'])}"] + [f"{k}: rel {e:.2e} cos {c:.6f}" for e, c, k in worst[:20]])
+    assert err < 1e-2 and abs(loss.item() - float(g["loss"])) < 1e-3 * abs(float(g["loss"]))
+    assert worst[0][0] < 8e-2 and min(c for _, c, _ in worst) > 0.995, worst[:3]
+
+
 def test_w48_eval_fp32_vs_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "g8_w48.npz"))
     m = _load_synth(PoseHighResolutionNet("w48", "fp32")).cuda().eval()

@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 from stlpose_amd import capi  # noqa: E402
 from stlpose_amd.engine import choose_tile  # noqa: E402
 
-DT = {"fp32": (capi.F32, torch.float32, 2e-4), "bf16": (capi.BF16, torch.bfloat16, 3e-2)}
+DT = {"fp32": (capi.F32, torch.float32, 2e-4), "bf16": (capi.BF16, torch.bfloat16, 3e-2), "f16": (capi.F16, torch.float16, 4e-3),
+      "mixed": (capi.BF16, torch.bfloat16, 3e-2)}   # mixed: GRADIENT tensors bf16 (this entry), forward tensors f16 (FDT)
+FDT = {"fp32": (capi.F32, torch.float32), "bf16": (capi.BF16, torch.bfloat16), "mixed": (capi.F16, torch.float16)}   # forward tensors
 EPS = 1e-5
 
 
@@ -71,7 +73,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("tile", ["auto", "explicit"])
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "f16"])
 @pytest.mark.parametrize("case", CONV_CASES + [(4, 48, 36, 32, 32, 3, 1), (4, 48, 36, 64, 64, 3, 1), (4, 24, 18, 128, 128, 3, 1),
                                                (4, 48, 36, 64, 256, 1, 1), (2, 12, 9, 256, 256, 3, 1)])
 def test_conv_forward_plain_and_stats(case, dt, tile):
@@ -105,23 +107,26 @@ def test_conv_forward_plain_and_stats(case, dt, tile):
     assert torch.allclose(sums[1], (stored * stored).sum(0), rtol=1e-5, atol=1e-3)
 
 
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "mixed"])
 @pytest.mark.parametrize("case", [(2, 24, 16, 32, 32, 3, 1), (2, 24, 18, 32, 64, 3, 2), (2, 8, 6, 128, 64, 1, 1),
                                   (4, 48, 36, 64, 64, 3, 1), (4, 24, 18, 128, 128, 3, 1), (2, 24, 18, 64, 256, 1, 1),
                                   (2, 24, 18, 96, 72, 3, 1)])
 def test_conv_bn_relu_chain_forward_backward(case, dt):
     """x --BN(relu) on load--> conv --> y ; backward: BN-backward on load, ReLU mask + r1/r2 in the
     data-gradient epilogue, weight gradient slabs.  Reference: torch autograd through
-    batch_norm(train) -> relu -> conv2d -> batch_norm(train)."""
+    batch_norm(train) -> relu -> conv2d -> batch_norm(train).  mixed: the forward tensors (x0, y, forward weights) are
+    f16, the gradients (dt, dx, data-gradient weights) bf16; the backward kernels read the forward tensors as `ydtype`."""
     code, td, tol = DT[dt]
+    fcode, ftd = FDT[dt]
+    ydt = fcode if fcode != code else 0
     B, H, W, Ci, Co, ks, s = case
     g = torch.Generator(device="cuda").manual_seed(2)
     pad = 1 if ks == 3 else 0
     x0 = torch.randn(B, Ci, H, W, device="cuda", generator=g) * 1.5 + 0.3
-    x0t = nhwc(x0, td)
+    x0t = nhwc(x0, ftd)
     x0r = x0t.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)  # the stored raw tensor
     w = (torch.randn(Co, Ci, ks, ks, device="cuda", generator=g) / math.sqrt(Ci * ks * ks))
-    wt = w.permute(0, 2, 3, 1).contiguous().to(td)
+    wt = w.permute(0, 2, 3, 1).contiguous().to(ftd)
     wr = wt.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
     g1 = (torch.rand(Ci, device="cuda", generator=g) + 0.5).requires_grad_(True)
     b1 = (torch.rand(Ci, device="cuda", generator=g) - 0.5).requires_grad_(True)
@@ -136,18 +141,18 @@ def test_conv_bn_relu_chain_forward_backward(case, dt):
     t.backward(dtt.float().permute(0, 3, 1, 2))
     # ---------------- HIP forward
     st1 = stats_of(x0t, Ci)
-    yk = torch.empty(B * Ho * Wo * Co, device="cuda", dtype=td)
+    yk = torch.empty(B * Ho * Wo * Co, device="cuda", dtype=ftd)
     st2 = torch.zeros(capi.NSHARD * 2 * Co, dtype=torch.float64, device="cuda")
     p = capi.Conv()
     p.shape = -1
-    p.dtype, p.B, p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.Co = code, B, H, W, Ci, Ho, Wo, Co
+    p.dtype, p.B, p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.Co = fcode, B, H, W, Ci, Ho, Wo, Co
     p.ks, p.stride = ks, s
     p.TH, p.TW = 0, 0
     p.src = bn_src(x0t, st1, g1.detach(), b1.detach(), B * H * W, True)
     p.w, p.out, p.out_stats = wt.data_ptr(), yk.data_ptr(), st2.data_ptr()
     capi.call("stl_conv_forward", C.byref(p), stream())
     torch.cuda.synchronize()
-    assert relerr(from_nhwc(yk, B, Ho, Wo, Co), y.detach()) < tol
+    assert relerr(from_nhwc(yk, B, Ho, Wo, Co), y.detach()) < (4e-3 if dt == "mixed" else tol)
     # ---------------- backward reductions for BN2 (what fuse_backward would have produced)
     ykf = yk.view(-1, Co).double()
     mean2 = ykf.mean(0)
@@ -163,9 +168,9 @@ def test_conv_bn_relu_chain_forward_backward(case, dt):
     # ---------------- weight gradient
     wg = capi.Wgrad()
     wg.dtype, wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = code, B, H, W, Ci, Ho, Wo, Co
-    wg.ks, wg.stride = ks, s
+    wg.ks, wg.stride, wg.ydtype = ks, s, ydt
     ctile = capi.lib().stl_wgrad_chunk(C.byref(wg))   # 64: wide-channel kernel variant (bf16 1x1 layers with Co, Ci >= 64)
-    assert ctile == (64 if (dt == "bf16" and ks == 1 and Ci >= 64 and Co >= 64) else 32)
+    assert ctile == (64 if (dt in ("bf16", "mixed") and ks == 1 and Ci >= 64 and Co >= 64) else 32)
     wg.TH, wg.TW = choose_tile(B, Ho, Wo, s, ks, x0t.element_size(), bn_cols=32, maxhalo=192 if ctile == 64 else 576)
     npt = math.ceil(B * (Ho + 1) / wg.TH) * math.ceil(Wo / wg.TW)
     wg.nsplit = min(3, npt)
@@ -183,7 +188,7 @@ def test_conv_bn_relu_chain_forward_backward(case, dt):
     d = capi.Conv()
     d.shape = -1
     d.dtype, d.B, d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.Co = code, B, Ho, Wo, Co, H, W, Ci
-    d.ks, d.stride, d.stuff = ks, 1, int(s == 2)
+    d.ks, d.stride, d.stuff, d.ydtype = ks, 1, int(s == 2), ydt
     d.TH, d.TW = 0, 0
     d.src, d.w, d.out = gs, wb.data_ptr(), dx.data_ptr()
     d.mask_y, d.mask_bn, d.red = x0t.data_ptr(), p.src, red.data_ptr()
@@ -580,7 +585,7 @@ def test_wgrad_group_equals_single_launches(case, dt, ws, monkeypatch):
     assert capi.lib().stl_conv_wgrad_group(C.byref(grp), stream()) != 0
 
 
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "f16"])
 @pytest.mark.parametrize("case", [(4, 48, 36, 32, 32), (4, 24, 18, 64, 64), (3, 24, 18, 128, 128), (2, 12, 16, 16, 16), (2, 10, 4, 48, 48), (2, 13, 7, 32, 64)])
 def test_conv_block_end_source_bnadd(case, dt):
     """STL_SRC_BNADD: z = ReLU(BN(y) + skip) formed while the 3x3 conv stages its input, and written out once
