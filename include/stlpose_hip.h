@@ -330,6 +330,13 @@ typedef struct stl_op {
 int stl_program_create(const stl_op* ops, int n, int nstreams, void** out_handle);
 int stl_program_run(void* program, void* const* streams /* hipStream_t[nstreams]; [0] = main */);
 int stl_program_destroy(void* program);
+/* The same program as ONE explicit HIP graph: stl_program_graph_build records every op's kernel launches (nothing runs) and
+ * adds them as kernel nodes with the program's dependencies (in-order streams + waits) -- built, not captured, because stream
+ * capture of a plan that forks onto three or more streams crashes in hipStreamEndCapture on ROCm 7.2; stl_program_graph_launch
+ * replays it on `stream`.  No events exist in this mode: stl_program_wait_op (the data-parallel bucket pick-up) needs
+ * stl_program_run. */
+int stl_program_graph_build(void* program);
+int stl_program_graph_launch(void* program, void* stream);
 /* Make `stream` wait for op `op` (which must record) of the LAST run of the program: how a
  * communication stream picks up a finished gradient bucket. */
 int stl_program_wait_op(void* program, int op, void* stream);

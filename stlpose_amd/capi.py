@@ -167,6 +167,8 @@ SIGNATURES = {
     "stl_program_run": [vp, C.POINTER(vp)],
     "stl_program_destroy": [vp],
     "stl_program_wait_op": [vp, i32, vp],
+    "stl_program_graph_build": [vp],
+    "stl_program_graph_launch": [vp, vp],
     "stl_selftest_mfma": [vp, vp],
     "stl_version": [],
 }

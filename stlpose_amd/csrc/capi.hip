@@ -33,3 +33,16 @@ void stl_note_kernel(const char* name, bool specific) {
     }
 }
 extern "C" const char* stl_last_kernel(void) { return g_kname; }
+
+thread_local StlRecorder* g_stl_recorder = nullptr;
+void stl_recorder_push(const StlLaunchRec& r) {
+    StlRecorder* rec = g_stl_recorder;
+    if (rec->n == rec->cap) {
+        const int cap = rec->cap ? 2 * rec->cap : 8;
+        StlLaunchRec* nr = new StlLaunchRec[cap];
+        for (int i = 0; i < rec->n; ++i) nr[i] = rec->recs[i];
+        delete[] rec->recs;
+        rec->recs = nr, rec->cap = cap;
+    }
+    rec->recs[rec->n++] = r;
+}

@@ -4,7 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <initializer_list>
+#include <tuple>
 #include <type_traits>
+#include <utility>
 #include "../../include/stlpose_hip.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -318,6 +320,44 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- launches: issued, or recorded for an explicit HIP graph
+// Every kernel of the library is launched through STL_LAUNCH.  Normally that is hipLaunchKernel on the caller's stream.  While a
+// program is being turned into a hipGraph (program.hip: stl_program_graph_build) a thread-local recorder is set and the launch
+// is RECORDED instead -- function, grid, block, LDS bytes and a private copy of the arguments -- to become a kernel node.
+struct StlLaunchRec {
+    const void* func;
+    dim3 grid, block;
+    size_t lds;
+    void* args_owner;                 // heap copy of the argument tuple (kept alive by the graph's owner)
+    void (*del)(void*);
+    void** params;                    // one pointer per kernel argument, into args_owner
+    int nparams;
+};
+struct StlRecorder { StlLaunchRec* recs; int n, cap; };
+extern thread_local StlRecorder* g_stl_recorder;
+void stl_recorder_push(const StlLaunchRec& r);
+
+template <typename Tup, size_t... I>
+static inline void stl_tuple_ptrs(Tup& t, void** out, std::index_sequence<I...>) { ((out[I] = (void*)&std::get<I>(t)), ...); }
+
+template <typename... KArgs, typename... Args>
+static inline void stl_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args&&... args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count");
+    using Tup = std::tuple<std::decay_t<KArgs>...>;
+    if (g_stl_recorder) {
+        Tup* t = new Tup(static_cast<std::decay_t<KArgs>>(args)...);
+        void** pp = new void*[sizeof...(KArgs) ? sizeof...(KArgs) : 1];
+        stl_tuple_ptrs(*t, pp, std::index_sequence_for<KArgs...>{});
+        stl_recorder_push(StlLaunchRec{(const void*)kernel, grid, block, lds, t, [](void* q) { delete static_cast<Tup*>(q); }, pp, (int)sizeof...(KArgs)});
+        return;
+    }
+    Tup t(static_cast<std::decay_t<KArgs>>(args)...);
+    void* pp[sizeof...(KArgs) ? sizeof...(KArgs) : 1];
+    stl_tuple_ptrs(t, pp, std::index_sequence_for<KArgs...>{});
+    (void)hipLaunchKernel((const void*)kernel, grid, block, pp, lds, st);
+}
+#define STL_LAUNCH(kernel, grid, block, lds, st, ...) stl_launch(kernel, grid, block, lds, st, ##__VA_ARGS__)
 
 // "base<bf16,a0,a1,...>" for stl_note_kernel (built once per instantiation: function-local static in the launcher)
 template <typename T>

@@ -476,7 +476,7 @@ int launch(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM, TY>), grid, dim3(64 * WM * WN), lds, st, k);
+    STL_LAUNCH((conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM, TY>), grid, dim3(64 * WM * WN), lds, st, k);
     static char nbuf[160];
     static const char* nm = stl_kname<T>(nbuf, "conv_core_kernel", {KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM, stl_code<TY>()});
     stl_note_kernel(nm, true);

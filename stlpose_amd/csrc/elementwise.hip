@@ -976,11 +976,11 @@ extern "C" int stl_fuse_forward(const stl_fuse* pp, void* stream) {
     const size_t lds = (size_t)p.nterms * 2 * p.C * 4;
     const dim3 grid(nblocks_for(total, 256, 2048));
     if (p.dtype == STL_BF16)
-        hipLaunchKernelGGL(fuse_fwd_kernel<__bf16>, grid, dim3(256), lds, ST, p);
+        STL_LAUNCH(fuse_fwd_kernel<__bf16>, grid, dim3(256), lds, ST, p);
     else if (p.dtype == STL_F16)
-        hipLaunchKernelGGL(fuse_fwd_kernel<f16>, grid, dim3(256), lds, ST, p);
+        STL_LAUNCH(fuse_fwd_kernel<f16>, grid, dim3(256), lds, ST, p);
     else
-        hipLaunchKernelGGL(fuse_fwd_kernel<float>, grid, dim3(256), lds, ST, p);
+        STL_LAUNCH(fuse_fwd_kernel<float>, grid, dim3(256), lds, ST, p);
     STL_LAUNCH_CHECK("fuse_forward");
     return 0;
 }
@@ -1006,11 +1006,11 @@ extern "C" int stl_fuse_backward(const stl_fuse_bwd* pp, void* stream) {
     const size_t lds = (size_t)(p.nbn > 0 ? p.nbn : 1) * 2 * p.C * 4 + (size_t)bd * 2 * 8 * 4;
     STL_CHECK(p.ydtype == 0 || p.ydtype == p.dtype || (p.dtype == STL_BF16 && p.ydtype == STL_F16), "fuse_bwd: ydtype %d does not go with dtype %d", p.ydtype, p.dtype);
     if (p.dtype == STL_BF16 && p.ydtype == STL_F16)
-        hipLaunchKernelGGL((fuse_bwd_kernel<__bf16, f16>), dim3(nb), dim3(bd), lds, ST, p);
+        STL_LAUNCH((fuse_bwd_kernel<__bf16, f16>), dim3(nb), dim3(bd), lds, ST, p);
     else if (p.dtype == STL_BF16)
-        hipLaunchKernelGGL(fuse_bwd_kernel<__bf16>, dim3(nb), dim3(bd), lds, ST, p);
+        STL_LAUNCH(fuse_bwd_kernel<__bf16>, dim3(nb), dim3(bd), lds, ST, p);
     else
-        hipLaunchKernelGGL(fuse_bwd_kernel<float>, dim3(nb), dim3(bd), lds, ST, p);
+        STL_LAUNCH(fuse_bwd_kernel<float>, dim3(nb), dim3(bd), lds, ST, p);
     STL_LAUNCH_CHECK("fuse_backward");
     return 0;
 }
@@ -1030,11 +1030,11 @@ extern "C" int stl_upsample_backward(const stl_upbwd* pp, void* stream) {
     const size_t lds = (size_t)2 * p.C * 4 + (size_t)bd * 2 * 8 * 4;
     STL_CHECK(p.ydtype == 0 || p.ydtype == p.dtype || (p.dtype == STL_BF16 && p.ydtype == STL_F16), "upsample_bwd: ydtype %d does not go with dtype %d", p.ydtype, p.dtype);
     if (p.dtype == STL_BF16 && p.ydtype == STL_F16)
-        hipLaunchKernelGGL((upsample_bwd_kernel<__bf16, f16>), dim3(nb), dim3(bd), lds, ST, p);
+        STL_LAUNCH((upsample_bwd_kernel<__bf16, f16>), dim3(nb), dim3(bd), lds, ST, p);
     else if (p.dtype == STL_BF16)
-        hipLaunchKernelGGL(upsample_bwd_kernel<__bf16>, dim3(nb), dim3(bd), lds, ST, p);
+        STL_LAUNCH(upsample_bwd_kernel<__bf16>, dim3(nb), dim3(bd), lds, ST, p);
     else
-        hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(nb), dim3(bd), lds, ST, p);
+        STL_LAUNCH(upsample_bwd_kernel<float>, dim3(nb), dim3(bd), lds, ST, p);
     STL_LAUNCH_CHECK("upsample_backward");
     return 0;
 }
@@ -1046,11 +1046,11 @@ extern "C" int stl_patch3x3(int dtype, const float* img, void* out, int B, int H
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const size_t total = (size_t)B * Ho * Wo * 4;
     if (dtype == STL_BF16)
-        hipLaunchKernelGGL(patch_kernel<__bf16>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, img, out, B, H, W, Ho, Wo, stride, mean3, std3);
+        STL_LAUNCH(patch_kernel<__bf16>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, img, out, B, H, W, Ho, Wo, stride, mean3, std3);
     else if (dtype == STL_F16)
-        hipLaunchKernelGGL(patch_kernel<f16>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, img, out, B, H, W, Ho, Wo, stride, mean3, std3);
+        STL_LAUNCH(patch_kernel<f16>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, img, out, B, H, W, Ho, Wo, stride, mean3, std3);
     else
-        hipLaunchKernelGGL(patch_kernel<float>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, img, out, B, H, W, Ho, Wo, stride, mean3, std3);
+        STL_LAUNCH(patch_kernel<float>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, img, out, B, H, W, Ho, Wo, stride, mean3, std3);
     STL_LAUNCH_CHECK("patch3x3");
     return 0;
 }
@@ -1062,7 +1062,7 @@ extern "C" int stl_head_forward(int dtype, const void* x, const float* w, const 
     const size_t P = (size_t)B * H * W;
     const size_t lds = (size_t)J * Ci * 4;
     const dim3 grid(nblocks_for(P));
-#define HF(T, JJ) hipLaunchKernelGGL((head_fwd_kernel<T, JJ>), grid, dim3(256), lds, ST, x, w, bias, out, B, H * W, Ci)
+#define HF(T, JJ) STL_LAUNCH((head_fwd_kernel<T, JJ>), grid, dim3(256), lds, ST, x, w, bias, out, B, H * W, Ci)
     if (dtype == STL_BF16) { if (J == 17) HF(__bf16, 17); else HF(__bf16, 16); }
     else if (dtype == STL_F16) { if (J == 17) HF(f16, 17); else HF(f16, 16); }
     else { if (J == 17) HF(float, 17); else HF(float, 16); }
@@ -1092,7 +1092,7 @@ extern "C" int stl_head_backward(int dtype2, const void* x, const float* w, cons
         hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<__bf16, 16, f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-#define HB(T, JJ, TY) hipLaunchKernelGGL((head_bwd_kernel<T, JJ, TY>), dim3(nblk), dim3(256), lds, ST, x, w, dout, dx, partial, B, H * W, Ci)
+#define HB(T, JJ, TY) STL_LAUNCH((head_bwd_kernel<T, JJ, TY>), dim3(nblk), dim3(256), lds, ST, x, w, dout, dx, partial, B, H * W, Ci)
     if (dtype == STL_BF16 && ydtype == STL_F16) { if (J == 17) HB(__bf16, 17, f16); else HB(__bf16, 16, f16); }
     else if (dtype == STL_BF16) { if (J == 17) HB(__bf16, 17, __bf16); else HB(__bf16, 16, __bf16); }
     else { if (J == 17) HB(float, 17, float); else HB(float, 16, float); }
@@ -1102,7 +1102,7 @@ extern "C" int stl_head_backward(int dtype2, const void* x, const float* w, cons
 }
 
 extern "C" int stl_sum_partials(const double* partial, int n, double scale, float* out, int accumulate, void* stream) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ST, partial, n, scale, out, accumulate);
+    STL_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, ST, partial, n, scale, out, accumulate);
     STL_LAUNCH_CHECK("sum_partials");
     return 0;
 }
@@ -1111,7 +1111,7 @@ extern "C" int stl_mse_loss(const float* out, const float* target, const float* 
                             int nblk, float* loss, int B, int J, int HW, float gscale, void* stream) {
     STL_CHECK(out && target && tweight && partial && loss && nblk >= 1, "mse: null pointer");
     const size_t n = (size_t)B * J * HW;
-    hipLaunchKernelGGL(mse_kernel, dim3(nblk), dim3(256), 0, ST, out, target, tweight, dout, partial, n, HW, gscale / (float)n);
+    STL_LAUNCH(mse_kernel, dim3(nblk), dim3(256), 0, ST, out, target, tweight, dout, partial, n, HW, gscale / (float)n);
     STL_LAUNCH_CHECK("mse_loss");
     return stl_sum_partials(partial, nblk, 0.5 / (double)n, loss, 0, stream);
 }
@@ -1119,7 +1119,7 @@ extern "C" int stl_mse_loss(const float* out, const float* target, const float* 
 extern "C" int stl_heatmap_argmax(const float* hm, int32_t* idx, float* maxval, float* preds, int BJ, int H, int W, void* stream) {
     if (BJ == 0) return 0;
     STL_CHECK(hm && maxval && preds && H > 0 && W > 0, "argmax: bad args");
-    hipLaunchKernelGGL(argmax_kernel, dim3(BJ), dim3(256), 0, ST, hm, idx, maxval, preds, H, W);
+    STL_LAUNCH(argmax_kernel, dim3(BJ), dim3(256), 0, ST, hm, idx, maxval, preds, H, W);
     STL_LAUNCH_CHECK("heatmap_argmax");
     return 0;
 }
@@ -1127,7 +1127,7 @@ extern "C" int stl_heatmap_argmax(const float* hm, int32_t* idx, float* maxval, 
 extern "C" int stl_final_preds(const float* hm, const float* center, const float* scale, float* preds, float* maxval, int B,
                                int J, int H, int W, void* stream) {
     if (B * J == 0) return 0;
-    hipLaunchKernelGGL(final_preds_kernel, dim3(B * J), dim3(256), 0, ST, hm, center, scale, preds, maxval, J, H, W);
+    STL_LAUNCH(final_preds_kernel, dim3(B * J), dim3(256), 0, ST, hm, center, scale, preds, maxval, J, H, W);
     STL_LAUNCH_CHECK("final_preds");
     return 0;
 }
@@ -1136,7 +1136,7 @@ extern "C" int stl_flip_merge(const float* a, const float* bflip, float* out, co
                               void* stream) {
     const size_t n = (size_t)B * J * H * W;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(flip_merge_kernel, dim3(nblocks_for(n)), dim3(256), 0, ST, a, bflip, out, perm, J, H, W, n);
+    STL_LAUNCH(flip_merge_kernel, dim3(nblocks_for(n)), dim3(256), 0, ST, a, bflip, out, perm, J, H, W, n);
     STL_LAUNCH_CHECK("flip_merge");
     return 0;
 }
@@ -1153,20 +1153,20 @@ extern "C" int stl_weight_prep_range(int dtype2, const float* master, void* wk, 
     const int dtype = dtype2 & 0xff, fdtype = (dtype2 >> 8) & 0xff;   // STL_DT2(type of the data-gradient layouts, type of the forward layouts)
     STL_CHECK(fdtype == 0 || fdtype == dtype || (dtype == STL_BF16 && fdtype == STL_F16), "weight_prep: forward type %d does not go with %d", fdtype, dtype);
     if (dtype == STL_BF16 && fdtype == STL_F16)
-        hipLaunchKernelGGL((weight_prep_kernel<__bf16, f16>), dim3(nblocks), dim3(256), 0, ST, master, (__bf16*)wk, tab, n, blk_base);
+        STL_LAUNCH((weight_prep_kernel<__bf16, f16>), dim3(nblocks), dim3(256), 0, ST, master, (__bf16*)wk, tab, n, blk_base);
     else if (dtype == STL_F16)
-        hipLaunchKernelGGL((weight_prep_kernel<f16, f16>), dim3(nblocks), dim3(256), 0, ST, master, (f16*)wk, tab, n, blk_base);
+        STL_LAUNCH((weight_prep_kernel<f16, f16>), dim3(nblocks), dim3(256), 0, ST, master, (f16*)wk, tab, n, blk_base);
     else if (dtype == STL_BF16)
-        hipLaunchKernelGGL(weight_prep_kernel<__bf16>, dim3(nblocks), dim3(256), 0, ST, master, (__bf16*)wk, tab, n, blk_base);
+        STL_LAUNCH(weight_prep_kernel<__bf16>, dim3(nblocks), dim3(256), 0, ST, master, (__bf16*)wk, tab, n, blk_base);
     else
-        hipLaunchKernelGGL(weight_prep_kernel<float>, dim3(nblocks), dim3(256), 0, ST, master, (float*)wk, tab, n, blk_base);
+        STL_LAUNCH(weight_prep_kernel<float>, dim3(nblocks), dim3(256), 0, ST, master, (float*)wk, tab, n, blk_base);
     STL_LAUNCH_CHECK("weight_prep_range");
     return 0;
 }
 
 extern "C" int stl_reduce_slabs(const float* partials, float* grads, const stl_slab* tab, int n, int nblocks, void* stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(nblocks), dim3(256), 0, ST, partials, grads, tab, n, 0);
+    STL_LAUNCH(reduce_slabs_kernel, dim3(nblocks), dim3(256), 0, ST, partials, grads, tab, n, 0);
     STL_LAUNCH_CHECK("reduce_slabs");
     return 0;
 }
@@ -1174,7 +1174,7 @@ extern "C" int stl_reduce_slabs(const float* partials, float* grads, const stl_s
 extern "C" int stl_reduce_slabs_range(const stl_reduce_range* r, void* stream) {
     STL_CHECK(r && r->partials && r->grads && r->tab && r->n >= 0 && r->nblocks >= 0, "reduce_slabs_range: bad arguments");
     if (r->n == 0 || r->nblocks == 0) return 0;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(r->nblocks), dim3(256), 0, ST, r->partials, r->grads, r->tab, r->n, r->blk_base);
+    STL_LAUNCH(reduce_slabs_kernel, dim3(r->nblocks), dim3(256), 0, ST, r->partials, r->grads, r->tab, r->n, r->blk_base);
     STL_LAUNCH_CHECK("reduce_slabs_range");
     return 0;
 }
@@ -1182,48 +1182,48 @@ extern "C" int stl_reduce_slabs_range(const stl_reduce_range* r, void* stream) {
 extern "C" int stl_bn_running_update(const double* stats, float* buffers, int64_t* nbt, const stl_bnrec* tab, int n,
                                      float momentum, void* stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(bn_running_kernel, dim3(n), dim3(256), 0, ST, stats, buffers, nbt, tab, momentum);
+    STL_LAUNCH(bn_running_kernel, dim3(n), dim3(256), 0, ST, stats, buffers, nbt, tab, momentum);
     STL_LAUNCH_CHECK("bn_running_update");
     return 0;
 }
 
 extern "C" int stl_bn_param_grads(const double* rstats, float* grads, const stl_bnrec* tab, int n, void* stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(bn_param_grads_kernel, dim3(n), dim3(256), 0, ST, rstats, grads, tab);
+    STL_LAUNCH(bn_param_grads_kernel, dim3(n), dim3(256), 0, ST, rstats, grads, tab);
     STL_LAUNCH_CHECK("bn_param_grads");
     return 0;
 }
 
 extern "C" int stl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, int32_t* step, void* stream) {
-    hipLaunchKernelGGL(inc_step_kernel, dim3(1), dim3(1), 0, ST, step);
-    hipLaunchKernelGGL(adam_kernel, dim3(nblocks_for((size_t)n, 256, 4096)), dim3(256), 0, ST, p, g, m, v, n, hyper, step);
+    STL_LAUNCH(inc_step_kernel, dim3(1), dim3(1), 0, ST, step);
+    STL_LAUNCH(adam_kernel, dim3(nblocks_for((size_t)n, 256, 4096)), dim3(256), 0, ST, p, g, m, v, n, hyper, step);
     STL_LAUNCH_CHECK("adam_step");
     return 0;
 }
 
 extern "C" int stl_sgd_step(float* p, const float* g, float* mom, int64_t n, const float* hyper, int32_t* step, void* stream) {
-    hipLaunchKernelGGL(inc_step_kernel, dim3(1), dim3(1), 0, ST, step);
-    hipLaunchKernelGGL(sgd_kernel, dim3(nblocks_for((size_t)n, 256, 4096)), dim3(256), 0, ST, p, g, mom, n, hyper, step);
+    STL_LAUNCH(inc_step_kernel, dim3(1), dim3(1), 0, ST, step);
+    STL_LAUNCH(sgd_kernel, dim3(nblocks_for((size_t)n, 256, 4096)), dim3(256), 0, ST, p, g, mom, n, hyper, step);
     STL_LAUNCH_CHECK("sgd_step");
     return 0;
 }
 
 extern "C" int stl_optim_begin_step(int32_t* step, void* stream) {
-    hipLaunchKernelGGL(inc_step_kernel, dim3(1), dim3(1), 0, ST, step);
+    STL_LAUNCH(inc_step_kernel, dim3(1), dim3(1), 0, ST, step);
     STL_LAUNCH_CHECK("optim_begin_step");
     return 0;
 }
 
 extern "C" int stl_adam_slice(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, const int32_t* step, void* stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(adam_kernel, dim3(nblocks_for((size_t)n, 256, 4096)), dim3(256), 0, ST, p, g, m, v, n, hyper, step);
+    STL_LAUNCH(adam_kernel, dim3(nblocks_for((size_t)n, 256, 4096)), dim3(256), 0, ST, p, g, m, v, n, hyper, step);
     STL_LAUNCH_CHECK("adam_slice");
     return 0;
 }
 
 extern "C" int stl_sgd_slice(float* p, const float* g, float* mom, int64_t n, const float* hyper, const int32_t* step, void* stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(sgd_kernel, dim3(nblocks_for((size_t)n, 256, 4096)), dim3(256), 0, ST, p, g, mom, n, hyper, step);
+    STL_LAUNCH(sgd_kernel, dim3(nblocks_for((size_t)n, 256, 4096)), dim3(256), 0, ST, p, g, mom, n, hyper, step);
     STL_LAUNCH_CHECK("sgd_slice");
     return 0;
 }
@@ -1261,7 +1261,7 @@ extern "C" int stl_gaussian_targets(const float* joints_xy, const float* vis, fl
     STL_CHECK(joints_xy && vis && target && tweight && B > 0 && J > 0 && Hh > 0 && Wh > 0, "gaussian_targets: bad arguments");
     STL_CHECK(sigma > 0.f && stride_x > 0.f && stride_y > 0.f, "gaussian_targets: sigma / stride must be positive");
     const size_t total = (size_t)B * J * Hh * Wh;
-    hipLaunchKernelGGL(gaussian_targets_kernel, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, joints_xy, vis, target, tweight,
+    STL_LAUNCH(gaussian_targets_kernel, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, joints_xy, vis, target, tweight,
                        B * J, Hh, Wh, (double)stride_x, (double)stride_y, sigma);
     STL_LAUNCH_CHECK("gaussian_targets");
     return 0;
@@ -1273,7 +1273,7 @@ extern "C" int stl_affine_crop(const uint8_t* src, const int64_t* src_off, const
     STL_CHECK(src && src_off && src_hw && minv && out && Ho > 0 && Wo > 0, "affine_crop: bad arguments");
     STL_CHECK((mean3 == nullptr) == (std3 == nullptr), "affine_crop: mean and std go together");
     const int gx = (Ho * Wo + 255) / 256;
-    hipLaunchKernelGGL(affine_crop_kernel, dim3(gx < 64 ? gx : 64, B), dim3(256), 0, ST, src, src_off, src_hw, minv, flip, out, Ho, Wo, mean3, std3);
+    STL_LAUNCH(affine_crop_kernel, dim3(gx < 64 ? gx : 64, B), dim3(256), 0, ST, src, src_off, src_hw, minv, flip, out, Ho, Wo, mean3, std3);
     STL_LAUNCH_CHECK("affine_crop");
     return 0;
 }
@@ -1282,9 +1282,9 @@ extern "C" int stl_maxpool2x2(int dtype, const void* x, void* out, int B, int H,
     STL_CHECK(C % 8 == 0 && H >= 2 && W >= 2, "maxpool: C%%8 == 0 and H, W >= 2 required");  // odd H/W: floor, like nn.MaxPool2d
     const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
     if (dtype == STL_BF16)
-        hipLaunchKernelGGL(maxpool_kernel<__bf16>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, x, out, B, H, W, C);
+        STL_LAUNCH(maxpool_kernel<__bf16>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, x, out, B, H, W, C);
     else
-        hipLaunchKernelGGL(maxpool_kernel<float>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, x, out, B, H, W, C);
+        STL_LAUNCH(maxpool_kernel<float>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, x, out, B, H, W, C);
     STL_LAUNCH_CHECK("maxpool2x2");
     return 0;
 }
@@ -1292,9 +1292,9 @@ extern "C" int stl_maxpool2x2(int dtype, const void* x, void* out, int B, int H,
 extern "C" int stl_l1_partial(int dtype, const void* a, const void* b, int64_t n, double* partial, int nblk, void* stream) {
     STL_CHECK(n % 8 == 0 && nblk >= 1, "l1: n%%8");
     if (dtype == STL_BF16)
-        hipLaunchKernelGGL((l1_kernel<__bf16, false>), dim3(nblk), dim3(256), 0, ST, a, b, (size_t)n / 8, partial);
+        STL_LAUNCH((l1_kernel<__bf16, false>), dim3(nblk), dim3(256), 0, ST, a, b, (size_t)n / 8, partial);
     else
-        hipLaunchKernelGGL((l1_kernel<float, false>), dim3(nblk), dim3(256), 0, ST, a, b, (size_t)n / 8, partial);
+        STL_LAUNCH((l1_kernel<float, false>), dim3(nblk), dim3(256), 0, ST, a, b, (size_t)n / 8, partial);
     STL_LAUNCH_CHECK("l1_partial");
     return 0;
 }
@@ -1302,16 +1302,16 @@ extern "C" int stl_l1_partial(int dtype, const void* a, const void* b, int64_t n
 extern "C" int stl_l2_partial(int dtype, const void* a, const void* b, int64_t n, double* partial, int nblk, void* stream) {
     STL_CHECK(n % 8 == 0 && nblk >= 1, "l2: n%%8");
     if (dtype == STL_BF16)
-        hipLaunchKernelGGL((l1_kernel<__bf16, true>), dim3(nblk), dim3(256), 0, ST, a, b, (size_t)n / 8, partial);
+        STL_LAUNCH((l1_kernel<__bf16, true>), dim3(nblk), dim3(256), 0, ST, a, b, (size_t)n / 8, partial);
     else
-        hipLaunchKernelGGL((l1_kernel<float, true>), dim3(nblk), dim3(256), 0, ST, a, b, (size_t)n / 8, partial);
+        STL_LAUNCH((l1_kernel<float, true>), dim3(nblk), dim3(256), 0, ST, a, b, (size_t)n / 8, partial);
     STL_LAUNCH_CHECK("l2_partial");
     return 0;
 }
 
 extern "C" int stl_bilinear_nchw(const float* in, float* out, int B, int C, int H, int W, int Ho, int Wo, void* stream) {
     const size_t total = (size_t)B * C * Ho * Wo;
-    hipLaunchKernelGGL(bilinear_kernel, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, in, out, B * C, H, W, Ho, Wo);
+    STL_LAUNCH(bilinear_kernel, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, in, out, B * C, H, W, Ho, Wo);
     STL_LAUNCH_CHECK("bilinear");
     return 0;
 }
@@ -1319,9 +1319,9 @@ extern "C" int stl_bilinear_nchw(const float* in, float* out, int B, int C, int 
 extern "C" int stl_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H, int W, void* stream) {
     const size_t total = (size_t)B * C * H * W;
     if (dtype == STL_BF16)
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, in, (__bf16*)out, B, C, H * W);
+        STL_LAUNCH(nchw_to_nhwc_kernel<__bf16>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, in, (__bf16*)out, B, C, H * W);
     else
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, in, (float*)out, B, C, H * W);
+        STL_LAUNCH(nchw_to_nhwc_kernel<float>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, in, (float*)out, B, C, H * W);
     STL_LAUNCH_CHECK("nchw_to_nhwc");
     return 0;
 }
@@ -1329,9 +1329,9 @@ extern "C" int stl_nchw_to_nhwc(int dtype, const float* in, void* out, int B, in
 extern "C" int stl_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H, int W, void* stream) {
     const size_t total = (size_t)B * C * H * W;
     if (dtype == STL_BF16)
-        hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, (const __bf16*)in, out, B, C, H * W);
+        STL_LAUNCH(nhwc_to_nchw_kernel<__bf16>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, (const __bf16*)in, out, B, C, H * W);
     else
-        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, (const float*)in, out, B, C, H * W);
+        STL_LAUNCH(nhwc_to_nchw_kernel<float>, dim3(nblocks_for(total, 256, 4096)), dim3(256), 0, ST, (const float*)in, out, B, C, H * W);
     STL_LAUNCH_CHECK("nhwc_to_nchw");
     return 0;
 }
@@ -1340,9 +1340,9 @@ extern "C" int stl_selftest_mfma(float* out, void* stream) {
     double* d = nullptr;
     if (hipMalloc(&d, 16) != hipSuccess) return stl_set_error("selftest: hipMalloc failed");
     hipMemsetAsync(d, 0, 16, ST);
-    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, ST, out);
-    hipLaunchKernelGGL(selftest_atomic_kernel, dim3(1), dim3(256), 0, ST, d);
-    hipLaunchKernelGGL(selftest_fin_kernel, dim3(1), dim3(1), 0, ST, d, out);
+    STL_LAUNCH(selftest_kernel, dim3(1), dim3(64), 0, ST, out);
+    STL_LAUNCH(selftest_atomic_kernel, dim3(1), dim3(256), 0, ST, d);
+    STL_LAUNCH(selftest_fin_kernel, dim3(1), dim3(1), 0, ST, d, out);
     hipStreamSynchronize(ST);
     hipFree(d);
     STL_LAUNCH_CHECK("selftest");

@@ -1,6 +1,7 @@
 // Native replay of a planned kernel program: one C call enqueues every launch of the forward or
 // backward plan on its HIP streams, with the cross-stream dependencies expressed as events.
 // (The Python planner builds the op list once; per step the host does O(1) Python work.)
+#include <string.h>
 #include <vector>
 #include "common.cuh"
 
@@ -12,6 +13,11 @@ struct Program {
     hipEvent_t fork = nullptr;
     std::vector<hipEvent_t> join;
     int nstreams = 1;
+    // explicit HIP graph of the program (stl_program_graph_build): one kernel node per recorded launch
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<StlLaunchRec> recs;   // own the argument copies the kernel nodes point at
+    int nnodes = 0;
 };
 }  // namespace
 
@@ -22,6 +28,53 @@ struct Program {
 // 14.69-14.71 ms per step with the default flags, 14.52-14.57 with hipEventDisableSystemFence, 14.66-14.71 with
 // hipEventReleaseToDevice; stream memory operations (hipStreamWriteValue32 / WaitValue32) instead of events: 15.45 (removed).
 static unsigned event_flags() { return hipEventDisableTiming | hipEventDisableSystemFence; }
+
+// one op of a program on stream `st` (also what the graph builder calls, with the launch recorder set)
+static int run_op(const stl_op& o, void* st, int i) {
+    int rc;
+        switch (o.kind) {
+            case STL_OP_CONV: rc = stl_conv_forward(static_cast<const stl_conv*>(o.desc), st); break;
+            case STL_OP_WGRAD: rc = stl_conv_wgrad(static_cast<const stl_wgrad*>(o.desc), st); break;
+            case STL_OP_WGRAD_GROUP: rc = stl_conv_wgrad_group(static_cast<const stl_wgrad_group*>(o.desc), st); break;
+            case STL_OP_FUSE: rc = stl_fuse_forward(static_cast<const stl_fuse*>(o.desc), st); break;
+            case STL_OP_FUSE_BWD: rc = stl_fuse_backward(static_cast<const stl_fuse_bwd*>(o.desc), st); break;
+            case STL_OP_UP_BWD: rc = stl_upsample_backward(static_cast<const stl_upbwd*>(o.desc), st); break;
+            case STL_OP_PATCH: {
+                const stl_patch* a = static_cast<const stl_patch*>(o.desc);
+                rc = stl_patch3x3(a->dtype, a->img, a->out, a->B, a->H, a->W, a->stride, a->mean3, a->std3, st);
+                break;
+            }
+            case STL_OP_HEAD: {
+                const stl_head* a = static_cast<const stl_head*>(o.desc);
+                rc = stl_head_forward(a->dtype, a->x, a->w, a->bias, a->out, a->B, a->H, a->W, a->Ci, a->J, st);
+                break;
+            }
+            case STL_OP_HEAD_BWD: {
+                const stl_head_bwd* a = static_cast<const stl_head_bwd*>(o.desc);
+                rc = stl_head_backward(a->dtype, a->x, a->w, a->dout, a->dx, a->partial, a->nblk, a->B, a->H, a->W, a->Ci, a->J, st);
+                break;
+            }
+            case STL_OP_OPTIM_SLICE: {
+                const stl_optim_slice* a = static_cast<const stl_optim_slice*>(o.desc);
+                rc = a->kind == 0 ? stl_adam_slice(a->p, a->g, a->m, a->v, a->n, a->hyper, a->step, st)
+                                  : stl_sgd_slice(a->p, a->g, a->m, a->n, a->hyper, a->step, st);
+                break;
+            }
+            case STL_OP_WPREP_RANGE: {
+                const stl_wprep_range* a = static_cast<const stl_wprep_range*>(o.desc);
+                rc = stl_weight_prep_range(a->dtype, a->master, a->wk, a->tab, a->n, a->blk_base, a->nblocks, st);
+                break;
+            }
+            case STL_OP_REDUCE_RANGE: rc = stl_reduce_slabs_range(static_cast<const stl_reduce_range*>(o.desc), st); break;
+            case STL_OP_BN_GRADS_RANGE: {
+                const stl_bn_range* a = static_cast<const stl_bn_range*>(o.desc);
+                rc = stl_bn_param_grads(a->rstats, a->grads, a->tab, a->n, st);
+                break;
+            }
+            default: return stl_set_error("program_run: op %d has unknown kind %d", i, o.kind);
+        }
+    return rc;
+}
 
 extern "C" int stl_program_create(const stl_op* ops, int n, int nstreams, void** out) {
     STL_CHECK(ops && out && n >= 0 && nstreams >= 1 && nstreams <= 16, "program_create: bad arguments");
@@ -64,6 +117,12 @@ extern "C" int stl_program_destroy(void* h) {
     if (!p) return 0;
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->join) (void)hipEventDestroy(e);
+    if (p->exec) (void)hipGraphExecDestroy(p->exec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
+    for (StlLaunchRec& r : p->recs) {
+        r.del(r.args_owner);
+        delete[] r.params;
+    }
     if (p->fork) (void)hipEventDestroy(p->fork);
     delete p;
     return 0;
@@ -91,48 +150,7 @@ extern "C" int stl_program_run(void* h, void* const* streams) {
         void* st = streams[o.stream];
         for (int w = 0; w < o.nwait; ++w)
             STL_CHECK(hipStreamWaitEvent((hipStream_t)st, p->ev[p->ev_of[o.wait[w]]], 0) == hipSuccess, "program_run: wait failed");
-        int rc;
-        switch (o.kind) {
-            case STL_OP_CONV: rc = stl_conv_forward(static_cast<const stl_conv*>(o.desc), st); break;
-            case STL_OP_WGRAD: rc = stl_conv_wgrad(static_cast<const stl_wgrad*>(o.desc), st); break;
-            case STL_OP_WGRAD_GROUP: rc = stl_conv_wgrad_group(static_cast<const stl_wgrad_group*>(o.desc), st); break;
-            case STL_OP_FUSE: rc = stl_fuse_forward(static_cast<const stl_fuse*>(o.desc), st); break;
-            case STL_OP_FUSE_BWD: rc = stl_fuse_backward(static_cast<const stl_fuse_bwd*>(o.desc), st); break;
-            case STL_OP_UP_BWD: rc = stl_upsample_backward(static_cast<const stl_upbwd*>(o.desc), st); break;
-            case STL_OP_PATCH: {
-                const stl_patch* a = static_cast<const stl_patch*>(o.desc);
-                rc = stl_patch3x3(a->dtype, a->img, a->out, a->B, a->H, a->W, a->stride, a->mean3, a->std3, st);
-                break;
-            }
-            case STL_OP_HEAD: {
-                const stl_head* a = static_cast<const stl_head*>(o.desc);
-                rc = stl_head_forward(a->dtype, a->x, a->w, a->bias, a->out, a->B, a->H, a->W, a->Ci, a->J, st);
-                break;
-            }
-            case STL_OP_HEAD_BWD: {
-                const stl_head_bwd* a = static_cast<const stl_head_bwd*>(o.desc);
-                rc = stl_head_backward(a->dtype, a->x, a->w, a->dout, a->dx, a->partial, a->nblk, a->B, a->H, a->W, a->Ci, a->J, st);
-                break;
-            }
-            case STL_OP_OPTIM_SLICE: {
-                const stl_optim_slice* a = static_cast<const stl_optim_slice*>(o.desc);
-                rc = a->kind == 0 ? stl_adam_slice(a->p, a->g, a->m, a->v, a->n, a->hyper, a->step, st)
-                                  : stl_sgd_slice(a->p, a->g, a->m, a->n, a->hyper, a->step, st);
-                break;
-            }
-            case STL_OP_WPREP_RANGE: {
-                const stl_wprep_range* a = static_cast<const stl_wprep_range*>(o.desc);
-                rc = stl_weight_prep_range(a->dtype, a->master, a->wk, a->tab, a->n, a->blk_base, a->nblocks, st);
-                break;
-            }
-            case STL_OP_REDUCE_RANGE: rc = stl_reduce_slabs_range(static_cast<const stl_reduce_range*>(o.desc), st); break;
-            case STL_OP_BN_GRADS_RANGE: {
-                const stl_bn_range* a = static_cast<const stl_bn_range*>(o.desc);
-                rc = stl_bn_param_grads(a->rstats, a->grads, a->tab, a->n, st);
-                break;
-            }
-            default: return stl_set_error("program_run: op %d has unknown kind %d", i, o.kind);
-        }
+        int rc = run_op(o, st, i);
         if (rc != 0) return rc;
         if (o.record) STL_CHECK(hipEventRecord(p->ev[p->ev_of[i]], (hipStream_t)st) == hipSuccess, "program_run: record failed");
     }
@@ -140,5 +158,69 @@ extern "C" int stl_program_run(void* h, void* const* streams) {
         STL_CHECK(hipEventRecord(p->join[s], (hipStream_t)streams[s]) == hipSuccess, "program_run: join record failed");
         STL_CHECK(hipStreamWaitEvent(main, p->join[s], 0) == hipSuccess, "program_run: join wait failed");
     }
+    return 0;
+}
+
+// ---- explicit HIP graph: the planner already knows every launch and every dependency, so the graph is
+// BUILT (hipGraphAddKernelNode + dependency lists), not captured -- stream capture of a plan that forks onto >= 3 streams
+// crashes inside hipStreamEndCapture on ROCm 7.2.  Every op is executed once with the launch recorder set (common.cuh,
+// STL_LAUNCH): its kernels become nodes, chained in issue order; the first node of an op depends on the last node of the
+// previous op of its stream (streams are in-order) and on the last node of every op it waits for.
+extern "C" int stl_program_graph_build(void* h) {
+    Program* p = static_cast<Program*>(h);
+    STL_CHECK(p, "program_graph_build: null program");
+    if (p->exec) return 0;
+    const int n = (int)p->ops.size();
+    STL_CHECK(hipGraphCreate(&p->graph, 0) == hipSuccess, "program_graph_build: hipGraphCreate failed");
+    std::vector<hipGraphNode_t> last_of_op(n, nullptr), last_of_stream(p->nstreams, nullptr);
+    for (int i = 0; i < n; ++i) {
+        const stl_op& o = p->ops[i];
+        StlRecorder rec{nullptr, 0, 0};
+        g_stl_recorder = &rec;
+        const int rc = run_op(o, nullptr, i);
+        g_stl_recorder = nullptr;
+        if (rc != 0) {
+            delete[] rec.recs;
+            return rc;
+        }
+        std::vector<hipGraphNode_t> deps;
+        if (last_of_stream[o.stream]) deps.push_back(last_of_stream[o.stream]);
+        for (int w = 0; w < o.nwait; ++w)
+            if (last_of_op[o.wait[w]]) deps.push_back(last_of_op[o.wait[w]]);
+        hipGraphNode_t prev = nullptr;
+        for (int k = 0; k < rec.n; ++k) {
+            const StlLaunchRec& r = rec.recs[k];
+            hipKernelNodeParams kp;
+            memset(&kp, 0, sizeof(kp));
+            kp.func = const_cast<void*>(r.func);
+            kp.gridDim = r.grid, kp.blockDim = r.block;
+            kp.sharedMemBytes = (unsigned)r.lds;
+            kp.kernelParams = r.params;
+            kp.extra = nullptr;
+            hipGraphNode_t node = nullptr;
+            hipError_t e = prev ? hipGraphAddKernelNode(&node, p->graph, &prev, 1, &kp)
+                                : hipGraphAddKernelNode(&node, p->graph, deps.empty() ? nullptr : deps.data(), deps.size(), &kp);
+            p->recs.push_back(r);
+            if (e != hipSuccess) {
+                delete[] rec.recs;
+                return stl_set_error("program_graph_build: hipGraphAddKernelNode failed for op %d (%s)", i, hipGetErrorString(e));
+            }
+            prev = node;
+            ++p->nnodes;
+        }
+        delete[] rec.recs;
+        if (prev) last_of_op[i] = prev, last_of_stream[o.stream] = prev;
+        else last_of_op[i] = last_of_stream[o.stream];   // an op without a launch: whoever waits on it waits on its predecessor
+    }
+    hipError_t e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
+    STL_CHECK(e == hipSuccess, "program_graph_build: hipGraphInstantiate failed (%s)", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int stl_program_graph_launch(void* h, void* stream) {
+    Program* p = static_cast<Program*>(h);
+    STL_CHECK(p && p->exec, "program_graph_launch: the program has no graph (stl_program_graph_build)");
+    hipError_t e = hipGraphLaunch(p->exec, (hipStream_t)stream);
+    STL_CHECK(e == hipSuccess, "program_graph_launch: %s", hipGetErrorString(e));
     return 0;
 }

@@ -430,7 +430,7 @@ int launch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((wgrad_kernel<T, KS, NVH, GQ, TPX, OCC, NW, TY>), grid, dim3(64 * NW), lds, st, k);
+    STL_LAUNCH((wgrad_kernel<T, KS, NVH, GQ, TPX, OCC, NW, TY>), grid, dim3(64 * NW), lds, st, k);
     static char nbuf[160];
     static const char* nm = stl_kname<T>(nbuf, "wgrad_kernel", {KS, NVH, GQ, TPX, OCC, NW, stl_code<TY>()});
     stl_note_kernel(nm, true);
@@ -679,7 +679,7 @@ int launch64(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((wgrad64_kernel<T, KS, NVH, GQ, TPX, TY>), grid, dim3(256), lds, st, k);
+    STL_LAUNCH((wgrad64_kernel<T, KS, NVH, GQ, TPX, TY>), grid, dim3(256), lds, st, k);
     static char nbuf[160];
     static const char* nm = stl_kname<T>(nbuf, "wgrad64_kernel", {KS, NVH, GQ, TPX, stl_code<TY>()});
     stl_note_kernel(nm, true);

@@ -182,6 +182,10 @@ class Engine:
         # members per grouped launch (round 3 at 256 blocks: 1 / 2 / 4 / 8 = 15.87 / 15.64 / 16.03 / 17.51; 4 at 512 blocks: 15.36)
         self.wgrad_group = int(env("STLPOSE_WGRAD_GROUP", "4"))
         self.skip_wgrad = env("STLPOSE_SKIP_WGRAD", "0") != "0"   # calibration only (wrong numerics): no weight-gradient launches
+        # STLPOSE_GRAPH=1: replay each program as ONE explicit HIP graph (csrc/program.hip: kernel nodes + the planner's
+        # dependencies) instead of launches and events on four streams
+        self.graph_mode = env("STLPOSE_GRAPH", "0") != "0"
+        self._graphs = set()
         self._poison = env("STLPOSE_POISON", "0") != "0"          # debug: planned buffers start as NaNs (see _alloc)
         self._stream = 0
         self._side = None
@@ -772,6 +776,12 @@ class Engine:
         exchange module (and, in backward, the weight gradients) run concurrently; fork/join and
         cross-stream dependencies are HIP events inside stl_program_run."""
         h = self._program(ops)
+        if self.graph_mode and ops is not getattr(self, "bwd_ops_events", None):
+            if id(ops) not in self._graphs:
+                capi.call("stl_program_graph_build", h)
+                self._graphs.add(id(ops))
+            capi.call("stl_program_graph_launch", h, stream)
+            return
         if self._side is None:
             self._make_streams()
         self._stream_arr[0] = stream

@@ -46,6 +46,8 @@ class TrainStep:
         self.dp = (FlatAllReduce(self.store.grads, process_group, bucket_mb, bounds=[(b["lo"], b["hi"]) for b in self.eng.buckets],
                                  bf16_buckets=bf16_buckets)
                    if process_group is not None else None)
+        if self.dp is not None:
+            self.eng.graph_mode = False   # the per-bucket all-reduce picks buckets up at the program's EVENTS (stl_program_wait_op)
         self._comm: Optional[torch.cuda.Stream] = None
         self._force_dp = os.environ.get("STLPOSE_DP_FORCE", "0") == "1"   # exercise the DP path with one rank (tests)
         self.world = self.dp.world if self.dp is not None else 1

@@ -157,7 +157,8 @@ def test_backward_stream_layouts_give_the_same_gradients(monkeypatch):
         return l, g, n
     l0, g0, n0 = run({})
     assert n0 == 4
-    for env, nstreams in (({"STLPOSE_STREAMS": "2"}, 2), ({"STLPOSE_STREAMS": "1"}, 1), ({"STLPOSE_WGRAD_GROUP": "1"}, 4)):
+    # STLPOSE_GRAPH=1: both programs as explicit HIP graphs (kernel nodes + the planner's dependencies, csrc/program.hip)
+    for env, nstreams in (({"STLPOSE_STREAMS": "2"}, 2), ({"STLPOSE_STREAMS": "1"}, 1), ({"STLPOSE_WGRAD_GROUP": "1"}, 4), ({"STLPOSE_GRAPH": "1"}, 4)):
         l1, g1, n1 = run(env)
         assert n1 == nstreams, (env, n1)
         assert l1 == l0, env
