@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 FLOPS_PER_IMG = {("w32", 384, 288): 103.11e9, ("w32", 256, 192): 45.83e9, ("w48", 384, 288): 211.74e9,
                  ("w48", 256, 192): 94.11e9}  # fwd + dgrad + wgrad, convs only
 MFMA_PEAK_BF16 = 2500.0  # TFLOP/s dense (MI355X_MICROARCH.md; the f16 MFMA forms take the same cycles)
+DUMP_OPS = ""
 DTYPE_LABEL = {"mixed": "f16/bf16", "bf16": "bf16", "fp32": "f32"}   # mixed: forward tensors + forward MFMA operands f16, gradients bf16, fp32 accumulate
 HBM_PEAK = 8000.0        # GB/s
 
@@ -103,6 +104,16 @@ def time_kernel_families(ts):
         f["bytes"] += by
     for (h, _arr, name, d), (_e0, _e1, kern, *_r) in zip(progs, evs):
         fams[kern]["replay"].append(h)
+    if DUMP_OPS:   # --dump-ops FILE: one line per launch (isolated duration, kernel, shape) for the analysis in DESIGN.md
+        with open(DUMP_OPS, "w") as fo:
+            for e0, e1, kern, name, d in evs:
+                m = d.members[0] if name == "stl_conv_wgrad_group" else d
+                shape = " ".join(f"{k}={getattr(m, k)}" for k in ("B", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "ks", "stride", "stuff", "H", "W", "C", "nterms", "ngrads", "shift", "nsplit") if hasattr(m, k))
+                extra = f" n={d.n}" if name == "stl_conv_wgrad_group" else ""
+                if name == "stl_conv_forward":
+                    extra = f" src={d.src.mode} mask_y={int(bool(d.mask_y))} addend={int(bool(d.addend))} mask_z={int(bool(d.mask_z))} shape={d.shape} tile={d.TH}x{d.TW}"
+                fl, by = cost(name, d)
+                fo.write(f"{e0.elapsed_time(e1) * 1e3:8.1f} us  {name:24s} {kern:52s} {shape}{extra}  flops={fl:.3e} bytes={by:.3e}\n")
     return sorted(fams.values(), key=lambda f: -f["ms"]), progs
 
 
@@ -387,7 +398,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32-path and VGG cfg4 legs")
+    ap.add_argument("--dump-ops", default="", help="write the isolated duration of every launch of one step to this file")
     a = ap.parse_args()
+    global DUMP_OPS
+    DUMP_OPS = a.dump_ops
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: start the N ranks as CHILD processes (one per GPU, RCCL)
