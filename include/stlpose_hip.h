@@ -329,6 +329,9 @@ typedef struct stl_op {
 } stl_op;
 int stl_program_create(const stl_op* ops, int n, int nstreams, void** out_handle);
 int stl_program_run(void* program, void* const* streams /* hipStream_t[nstreams]; [0] = main */);
+/* Ops [first, last) only; first == 0 forks the side streams, last == n joins them.  A data-parallel host runs the backward program
+ * bucket by bucket and enqueues each bucket's all-reduce between two ranges, i.e. right behind the bucket in every in-order queue. */
+int stl_program_run_range(void* program, void* const* streams, int first, int last);
 int stl_program_destroy(void* program);
 /* The same program as ONE explicit HIP graph: stl_program_graph_build records every op's kernel launches (nothing runs) and
  * adds them as kernel nodes with the program's dependencies (in-order streams + waits) -- built, not captured, because stream

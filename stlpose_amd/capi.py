@@ -165,6 +165,7 @@ SIGNATURES = {
     "stl_nhwc_to_nchw": [i32, vp, vp, i32, i32, i32, i32, vp],
     "stl_program_create": [C.POINTER(Op), i32, i32, C.POINTER(vp)],
     "stl_program_run": [vp, C.POINTER(vp)],
+    "stl_program_run_range": [vp, C.POINTER(vp), i32, i32],
     "stl_program_destroy": [vp],
     "stl_program_wait_op": [vp, i32, vp],
     "stl_program_graph_build": [vp],

@@ -135,17 +135,24 @@ extern "C" int stl_program_wait_op(void* h, int op, void* stream) {
     return 0;
 }
 
-extern "C" int stl_program_run(void* h, void* const* streams) {
+// ops [first, last) of the program; the first range forks the side streams off the main stream, the last one joins them.
+// Splitting a run lets the host put other work between two ranges IN ISSUE ORDER: hardware queues are in-order and the
+// communication stream of a data-parallel run shares one with a compute stream (GPU_MAX_HW_QUEUES = 4), so a gradient bucket's
+// all-reduce must be ENQUEUED right behind the bucket's last op -- issued after the whole backward program it would sit behind
+// everything that queue still has to run (measured with a stand-in kernel, profiles/r04_dp_overlap*.txt: bucket 0 final at
+// 6.3 ms, its communication-stream kernel started at 13.9 ms).
+extern "C" int stl_program_run_range(void* h, void* const* streams, int first, int last) {
     Program* p = static_cast<Program*>(h);
     STL_CHECK(p && streams, "program_run: null program");
+    const int n = (int)p->ops.size();
+    STL_CHECK(first >= 0 && first <= last && last <= n, "program_run_range: bad range [%d, %d) of %d ops", first, last, n);
     hipStream_t main = (hipStream_t)streams[0];
-    if (p->nstreams > 1) {
+    if (first == 0 && p->nstreams > 1) {
         STL_CHECK(hipEventRecord(p->fork, main) == hipSuccess, "program_run: fork record failed");
         for (int s = 1; s < p->nstreams; ++s)
             STL_CHECK(hipStreamWaitEvent((hipStream_t)streams[s], p->fork, 0) == hipSuccess, "program_run: fork wait failed");
     }
-    const int n = (int)p->ops.size();
-    for (int i = 0; i < n; ++i) {
+    for (int i = first; i < last; ++i) {
         const stl_op& o = p->ops[i];
         void* st = streams[o.stream];
         for (int w = 0; w < o.nwait; ++w)
@@ -154,11 +161,19 @@ extern "C" int stl_program_run(void* h, void* const* streams) {
         if (rc != 0) return rc;
         if (o.record) STL_CHECK(hipEventRecord(p->ev[p->ev_of[i]], (hipStream_t)st) == hipSuccess, "program_run: record failed");
     }
-    for (int s = 1; s < p->nstreams; ++s) {
-        STL_CHECK(hipEventRecord(p->join[s], (hipStream_t)streams[s]) == hipSuccess, "program_run: join record failed");
-        STL_CHECK(hipStreamWaitEvent(main, p->join[s], 0) == hipSuccess, "program_run: join wait failed");
+    if (last == n) {
+        for (int s = 1; s < p->nstreams; ++s) {
+            STL_CHECK(hipEventRecord(p->join[s], (hipStream_t)streams[s]) == hipSuccess, "program_run: join record failed");
+            STL_CHECK(hipStreamWaitEvent(main, p->join[s], 0) == hipSuccess, "program_run: join wait failed");
+        }
     }
     return 0;
+}
+
+extern "C" int stl_program_run(void* h, void* const* streams) {
+    Program* p = static_cast<Program*>(h);
+    STL_CHECK(p && streams, "program_run: null program");
+    return stl_program_run_range(h, streams, 0, (int)p->ops.size());
 }
 
 // ---- explicit HIP graph: the planner already knows every launch and every dependency, so the graph is

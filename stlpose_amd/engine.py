@@ -842,12 +842,26 @@ class Engine:
             capi.call("stl_bn_running_update", self.stats.data_ptr(), st.bufs.data_ptr(), st.nbt.data_ptr(),
                       self._bn_tab.data_ptr(), len(self.bns), MOMENTUM, stream)
 
-    def backward(self, stream: int, fused_optim: bool = False):
+    def backward(self, stream: int, fused_optim: bool = False, on_bucket=None):
         """expects self.dout filled; leaves dL/dparam in store.grads (overwrites).  fused_optim: the program of
-        attach_optimizer (optimiser + next step's weight layouts inside backward)."""
+        attach_optimizer (optimiser + next step's weight layouts inside backward).  on_bucket(i): called on the host right after
+        gradient bucket i's last op has been ENQUEUED (the program is issued range by range, stl_program_run_range): the
+        data-parallel path enqueues the bucket's all-reduce there, so that in every in-order hardware queue it sits directly
+        behind the bucket instead of behind the rest of backward."""
         assert self.training
-        st = self.store
         self.rstats.zero_()
+        if on_bucket is not None and not fused_optim and self.buckets:
+            h = self._program(self.bwd_ops)
+            if self._side is None:
+                self._make_streams()
+            self._stream_arr[0] = stream
+            first = 0
+            for op_idx, i in sorted((b["op"], i) for i, b in enumerate(self.buckets)):
+                capi.call("stl_program_run_range", h, self._stream_arr, first, op_idx + 1)
+                first = op_idx + 1
+                on_bucket(i)
+            capi.call("stl_program_run_range", h, self._stream_arr, first, len(self.bwd_ops))
+            return
         self._run(self.bwd_ops_opt if fused_optim else self.bwd_ops, stream)   # includes the per-bucket slab reductions and BatchNorm gradients
 
     def attach_optimizer(self, kind: int, p: int, g: int, m: int, v: int, hyper: int, step: int):

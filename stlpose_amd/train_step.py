@@ -125,7 +125,9 @@ class TrainStep:
             self.loss.mul_(self._loss_scale).add_(self._loss_offset)
         if fused_optim:
             capi.call("stl_optim_begin_step", self.step_count.data_ptr(), st)
-        e.backward(st, fused_optim=fused_optim)
+        dp_on = self.dp is not None and (self.world > 1 or self._force_dp) and not self.use_graph
+        e.backward(st, fused_optim=fused_optim, on_bucket=self._issue_bucket if dp_on else None)
+        self._buckets_issued = dp_on
         if fused_optim:
             self._prepped = True   # every bucket's kernel-layout weights were refreshed inside the program
 
@@ -139,20 +141,27 @@ class TrainStep:
             capi.call("stl_sgd_step", s.master.data_ptr(), s.grads.data_ptr(), self.m.data_ptr(), s.nparam,
                       self.hyper.data_ptr(), self.step_count.data_ptr(), st)
 
-    def _allreduce(self):
-        """Bucketed all-reduce overlapped with backward: the backward program is already ENQUEUED when
-        this runs; every bucket's collective is issued on a communication stream that waits for the
-        event recorded after that bucket's slab reduction, so RCCL works on the last layers'
-        gradients while the data-gradient chain is still in the early layers.  The main stream then
-        waits for all collectives before the optimiser."""
-        if self.dp is None or (self.world == 1 and not self._force_dp):
-            return
+    def _issue_bucket(self, i: int):
+        """Enqueue gradient bucket i's all-reduce on the communication stream, behind the bucket's event.  Called by
+        Engine.backward between two ranges of the backward program, i.e. while the host is still ENQUEUING backward: hardware
+        queues are in-order and RCCL's stream shares one with a compute stream (GPU_MAX_HW_QUEUES = 4), so a collective issued
+        after the whole program would sit behind everything that queue still has to run (round 4, measured with a stand-in
+        kernel on the communication stream: bucket 0 final at 6.3 ms, its kernel started at 13.9 ms -- no overlap at all)."""
         if self._comm is None:
             self._comm = torch.cuda.Stream(device=self.dev)
-        for i in range(len(self.eng.buckets)):
-            self.eng.bucket_wait(i, self._comm.cuda_stream)
-            with torch.cuda.stream(self._comm):
-                self.dp.launch(upto=i + 1, force=self._force_dp)
+        self.eng.bucket_wait(i, self._comm.cuda_stream)
+        with torch.cuda.stream(self._comm):
+            self.dp.launch(upto=i + 1, force=self._force_dp)
+
+    def _allreduce(self):
+        """Bucketed all-reduce overlapped with backward.  The collectives were enqueued bucket by bucket while backward was
+        being issued (_issue_bucket); here the main stream waits for them before the optimiser.  (Graph mode: the buckets'
+        events do not exist, the collectives are issued here, behind the whole backward.)"""
+        if self.dp is None or (self.world == 1 and not self._force_dp):
+            return
+        if not getattr(self, "_buckets_issued", False):
+            for i in range(len(self.eng.buckets)):
+                self._issue_bucket(i)
         self.dp.wait()
 
     def _capture(self):

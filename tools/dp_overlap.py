@@ -21,12 +21,28 @@ for line in op(f, "rt"):
 rows.sort(key=lambda r: r["s"])
 adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["name"]]
 assert len(adam) >= 2, "need two optimiser launches to window one step"
-win = rows[adam[-2] + 1: adam[-1] + 1]
-t0 = win[0]["s"]
 is_coll = lambda n: "nccl" in n.lower() or "rccl" in n.lower() or "allreduce" in n.lower()   # noqa: E731
-colls = [r for r in win if is_coll(r["name"])]
+# A ONE-rank communicator launches no kernel for an all-reduce.  With STLPOSE_BF16_BUCKETS=1 the communication stream still
+# carries, per bucket and behind the same event, the fp32 -> bf16 staging copy of the bucket (dp.FlatAllReduce._send): that
+# kernel stands in for the collective's start.
+is_stand_in = lambda n: "bfloat16_copy_kernel" in n   # noqa: E731
+win, colls, stand_in = None, [], False
+for k in range(len(adam) - 1, 0, -1):   # the LAST step that carries collectives (bench.py ends with steps that have them switched off)
+    w = rows[adam[k - 1] + 1: adam[k] + 1]
+    c = [r for r in w if is_coll(r["name"])]
+    if not c:
+        c = [r for r in w if is_stand_in(r["name"])]
+        if c:
+            stand_in = True
+    nb = sum(1 for r in w if "bn_param_grads" in r["name"])
+    if c and len(c) == nb:   # exactly one per bucket: a real step (bench.py's per-bucket timing loop issues three per bucket)
+        win, colls = w, c
+        break
+assert win is not None, "no step with a collective (or its stand-in) in the trace: run with STLPOSE_DP_FORCE=1 [STLPOSE_BF16_BUCKETS=1]"
+t0 = win[0]["s"]
 buckets = [r for r in win if "bn_param_grads" in r["name"]]
-lines = [f"step window: {len(win)} kernels, wall {(max(r['e'] for r in win) - t0) / 1e6:.3f} ms; {len(buckets)} gradient buckets, {len(colls)} collective kernels",
+lines = ["(no RCCL kernel in the trace: one-rank communicator; the bucket's bf16 staging copy on the communication stream stands in for the collective)"] if stand_in else []
+lines += [f"step window: {len(win)} kernels, wall {(max(r['e'] for r in win) - t0) / 1e6:.3f} ms; {len(buckets)} gradient buckets, {len(colls)} collective kernels",
          "bucket  final at (ms)  collective start (ms)  gap (us)  collective (us)  queue(bucket/coll)  kernels on the collective's queue in the gap"]
 used = set()
 for i, b in enumerate(buckets):

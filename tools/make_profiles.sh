@@ -22,7 +22,7 @@ echo traffic passes done
 timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -- $B --steps 2 --warmup 1 > $OUT/pmc_mfma.log 2>&1 || echo "mfma pass failed (rc $?)"
 echo mfma pass done
 # 5. one-rank RCCL rehearsal of the bucketed all-reduce: when does each bucket's collective start? (tools/dp_overlap.py)
-STLPOSE_DP_FORCE=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_dp -- $B --steps 5 --warmup 3 > $OUT/trace_dp.log 2>&1 || echo "dp trace failed (rc $?)"
+STLPOSE_DP_FORCE=1 STLPOSE_BF16_BUCKETS=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_dp -- $B --steps 5 --warmup 3 > $OUT/trace_dp.log 2>&1 || echo "dp trace failed (rc $?)"
 # summaries (small; the raw traces stay on the box except gzipped kernel traces)
 for d in trace_default trace_serial; do
   f=$(ls $OUT/$d/*/*kernel_trace.csv | head -1); gzip -c $f > $OUT/${R}_$d.csv.gz
