@@ -211,6 +211,29 @@ def test_tiny_mixed_full_gradients_vs_reference_golden(golden_dir):
     assert errs.max() < 0.6 and np.median(errs) < 0.15 and min(c for _, c, _ in worst) > 0.985, worst[:3]
 
 
+@pytest.mark.parametrize("dt", ["fp32", "mixed"])
+def test_poisoned_plan_buffers_change_nothing(golden_dir, dt, monkeypatch):
+    """STLPOSE_POISON=1: every planned activation / gradient buffer starts as NaNs.  Output, loss and every gradient must come
+    out as in the clean run, bit for bit: no kernel consumes a location that nobody wrote (halo slots, tile padding, unused
+    channel tails are masked AFTER they are loaded)."""
+    g = np.load(os.path.join(golden_dir, "g1_tiny_train.npz"))
+
+    def run(poison):
+        monkeypatch.setenv("STLPOSE_POISON", poison)
+        m = _load_synth(PoseHighResolutionNet("tiny", dt)).cuda().train()
+        out = m(torch.from_numpy(g["img"]).cuda())
+        loss = PersonMSELoss()(out, torch.from_numpy(g["target"]).cuda(), torch.from_numpy(g["target_weight"]).cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+    o0, g0 = run("0")
+    o1, g1 = run("1")
+    assert not torch.isnan(o1).any() and not torch.isnan(g1).any()
+    assert torch.equal(o0, o1)
+    # gradients: the fp64 statistics atomics arrive in a different order from run to run
+    assert float((g0 - g1).abs().max()) <= 1e-5 * float(g0.abs().max())
+
+
 def test_w48_eval_fp32_vs_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "g8_w48.npz"))
     m = _load_synth(PoseHighResolutionNet("w48", "fp32")).cuda().eval()
