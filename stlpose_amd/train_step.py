@@ -49,6 +49,10 @@ class TrainStep:
         if self.dp is not None:
             self.eng.graph_mode = False   # the per-bucket all-reduce picks buckets up at the program's EVENTS (stl_program_wait_op)
         self._comm: Optional[torch.cuda.Stream] = None
+        self._dp_backend = ""
+        if process_group is not None:
+            import torch.distributed as dist
+            self._dp_backend = str(dist.get_backend(process_group))
         self._force_dp = os.environ.get("STLPOSE_DP_FORCE", "0") == "1"   # exercise the DP path with one rank (tests)
         self.world = self.dp.world if self.dp is not None else 1
         n = self.store.nparam
@@ -125,7 +129,9 @@ class TrainStep:
             self.loss.mul_(self._loss_scale).add_(self._loss_offset)
         if fused_optim:
             capi.call("stl_optim_begin_step", self.step_count.data_ptr(), st)
-        dp_on = self.dp is not None and (self.world > 1 or self._force_dp) and not self.use_graph
+        # per-bucket issue while backward is being enqueued: RCCL only ("nccl": the collective is a kernel enqueued on the
+        # communicator's stream, the host does not wait); gloo's all-reduce of a device tensor makes the host wait for the stream
+        dp_on = self.dp is not None and (self.world > 1 or self._force_dp) and not self.use_graph and self._dp_backend == "nccl"
         e.backward(st, fused_optim=fused_optim, on_bucket=self._issue_bucket if dp_on else None)
         self._buckets_issued = dp_on
         if fused_optim:
