@@ -198,6 +198,37 @@ def test_w48_train_fp32_vs_reference_golden(golden_dir):
     np.testing.assert_allclose(bn, g["buffernorm_all"], rtol=1e-3)
 
 
+def test_w48_train_mixed_vs_reference_golden(golden_dir):
+    """W48 (48 / 96 / 192 / 384 channels: every channel count ends in a ragged 64-byte chunk) through the MIXED mode against the
+    reference's training fixture: the masked channel tails of the f16 forward kernels and of the backward kernels' second element
+    type.  Bars: the output like the W32 mixed test; gradients by direction (they are bf16 and the batch is 2 x 128 x 96)."""
+    g = np.load(os.path.join(golden_dir, "g8_w48_train.npz"))
+    img, tgt, tw = synth_batch(2, 128, 96, seed=48, sigma=2.0)
+    m = _load_synth(PoseHighResolutionNet("w48", "mixed")).cuda().train()
+    out = m(torch.from_numpy(img).cuda())
+    loss = PersonMSELoss()(out, torch.from_numpy(tgt).cuda(), torch.from_numpy(tw).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    o = out.detach().cpu().numpy()
+    err = np.abs(o.reshape(-1)[::16] - g["out_sample"]).max() / float(g["out_absmax"])
+    grads = {k: prm.grad for k, prm in m.named_parameters()}
+    cos = []
+    for k in g.files:
+        if k.startswith("grad/"):
+            a, b = grads[k[5:]].double().reshape(-1).cpu(), torch.from_numpy(g[k]).double().reshape(-1)
+            assert not torch.isnan(a).any(), k
+            cos.append((float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)), k))
+    cos.sort()
+    nrm = np.array([float(grads[k].double().norm()) for k in g["param_keys"]])
+    rel = np.abs(nrm - g["gradnorm_all"]) / (g["gradnorm_all"] + 1e-12)
+    _diag("diag_w48_train_mixed.txt", [f"out rel err {err:.3e}", f"loss {loss.item()} ref {float(g['loss'])}", f"gradnorm rel: median {np.median(rel):.2e} max {rel.max():.2e}"]
+          + [f"cos {c:.6f} {k}" for c, k in cos[:10]])
+    assert err < 1.2e-2, f"mixed-mode output error {err:.3e}"
+    assert abs(loss.item() - float(g["loss"])) < 1e-3 * abs(float(g["loss"]))
+    assert cos[0][0] > 0.97 and np.median([c for c, _ in cos]) > 0.99, (cos[:3], float(np.median([c for c, _ in cos])))   # measured 0.986 worst
+    assert np.median(rel) < 2e-2
+
+
 def test_w48_bf16_train_step_runs_at_cfg3_shape():
     """BASELINE configs[2] shape on one GPU (W48, 384x288, batch 32, bf16): the 48/96/192/384 widths at the full
     batch -- finite loss that decreases, finite gradients."""
