@@ -109,12 +109,16 @@ __device__ __forceinline__ int sdiv(int n, unsigned long long m) { return (int)(
 // z = ReLU(BN(x) + y); it is also written to p.src_out by the block that owns the pixel (tile interior, channel block 0).
 // PE: plain epilogue -- the launch has no bias / addend / mask operand (conv_common.inc, epilogue_apply).
 // TY: element type of the FORWARD tensors a data gradient reads (src.y, mask_y, mask_z); T everywhere else.
-template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, bool PE, int OCC, int WR, bool ZM = false, typename TY = T>
+// DB: two LDS images [halo | filters] (k.sz_a / k.sz_b apart) and ONE barrier per stage: while stage s is multiplied out of one
+// image, the staged registers of stage s + 1 are transformed and written into the other and the loads of stage s + 2 are
+// requested, one staging vector per tap of the MFMA loop (round 4; block shape 3).
+template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, bool PE, int OCC, int WR, bool ZM = false, typename TY = T, bool DB = false>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const ConvK k) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTHR = 64 * WM * WN;
     constexpr int KV = ET<T>::KV, CK = ET<T>::CK, TAPS = KS * KS;
     static_assert(!ZM || (Q && KS == 3), "block-end source: 3x3, two tensors on load");
+    static_assert(!DB || (!ZM && WR == 0 && KS == 3), "double-buffered image: 3x3, plain / BN / BNBWD sources, filters staged per chunk");
     constexpr int BCO = WN * NTW * 16;
     constexpr int ROWB = TAPS * 64 + 32;
     constexpr int NVB = (BCO * TAPS * 4 + NTHR - 1) / NTHR;
@@ -221,26 +225,33 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     int st_t, st_ch;      // the stage (tile, chunk) the set holds
     bool st_have;
 
-    auto tile_setup = [&](int t, int* go) {
+    // tile-uniform terms of tile t (scalar unit), then the element offset of staging slot i (-1: padding / outside)
+    auto tile_terms = [&](int t, int& y0, int& cb, int& b0) __attribute__((always_inline)) {
         const int tr = sdiv(t, k.m_tc), tc = t - tr * k.tiles_c;
-        const int vrs = tr * k.TH * k.seff, cb = tc * k.TW * k.seff - k.pad;
-        const int b0 = sdiv(vrs, k.m_PI), y0 = vrs - b0 * k.PI - k.pad;
+        const int vrs = tr * k.TH * k.seff;
+        cb = tc * k.TW * k.seff - k.pad;
+        b0 = sdiv(vrs, k.m_PI), y0 = vrs - b0 * k.PI - k.pad;
+    };
+    auto slot_go = [&](int rc, int y0, int cb, int b0) __attribute__((always_inline)) -> int {   // rc = a_rc[] of the slot
         const int n_PI = -k.PI;
-#pragma unroll
-        for (int i = 0; i < NVA; ++i) {
-            const int iy0 = y0 + (a_rc[i] >> 16);
-            int ix = cb + (a_rc[i] & 0xffff);
-            const int wr_ = fdiv(iy0 < 0 ? 0 : iy0, k.r_PI);
-            int iy = mad24_vsv(wr_, n_PI, iy0);
-            bool ok = (a_rc[i] >= 0) & (iy0 >= 0) & (ix >= 0) & (b0 + wr_ < p.B);
-            if (p.stuff) {   // zero-stuffed source (transposed convolution): only even rows / columns exist
-                ok = ok & !((iy | ix) & 1);
-                iy >>= 1, ix >>= 1;
-            }
-            ok = ok & (iy < p.Hi) & (ix < p.Wi);
-            const int e = madu24_vsv(madu24_vsv(madu24_vsv(b0 + wr_, p.Hi, iy), p.Wi, ix), p.Ci, a_part * KV);
-            go[i] = ok ? e : -1;
+        const int iy0 = y0 + (rc >> 16);
+        int ix = cb + (rc & 0xffff);
+        const int wr_ = fdiv(iy0 < 0 ? 0 : iy0, k.r_PI);
+        int iy = mad24_vsv(wr_, n_PI, iy0);
+        bool ok = (rc >= 0) & (iy0 >= 0) & (ix >= 0) & (b0 + wr_ < p.B);
+        if (p.stuff) {   // zero-stuffed source (transposed convolution): only even rows / columns exist
+            ok = ok & !((iy | ix) & 1);
+            iy >>= 1, ix >>= 1;
         }
+        ok = ok & (iy < p.Hi) & (ix < p.Wi);
+        const int e = madu24_vsv(madu24_vsv(madu24_vsv(b0 + wr_, p.Hi, iy), p.Wi, ix), p.Ci, a_part * KV);
+        return ok ? e : -1;
+    };
+    auto tile_setup = [&](int t, int* go) {
+        int y0, cb, b0;
+        tile_terms(t, y0, cb, b0);
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) go[i] = slot_go(a_rc[i], y0, cb, b0);
     };
     // Loads are UNCONDITIONAL (invalid slots read element 0 and are zeroed at write time): a
     // guarded load makes hipcc branch around it and wait vmcnt(0) per element, which serialises
@@ -325,17 +336,19 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
         }
     };
     STAMP(3);
-    prefetch();
-    if (wres) {
+    if constexpr (!DB) {
+        prefetch();
+        if (wres) {
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) {
-            const bool ok = b_g[i] >= 0 && (((tid + i * NTHR) & 3) * KV) < p.Ci;
-            V16 val = rb[i];
-            mask16(val, ok);
-            if (tid + i * NTHR < BCO * TAPS * 4) *reinterpret_cast<V16*>(sB + b_l[i]) = val;
+            for (int i = 0; i < NVB; ++i) {
+                const bool ok = b_g[i] >= 0 && (((tid + i * NTHR) & 3) * KV) < p.Ci;
+                V16 val = rb[i];
+                mask16(val, ok);
+                if (tid + i * NTHR < BCO * TAPS * 4) *reinterpret_cast<V16*>(sB + b_l[i]) = val;
+            }
         }
+        __syncthreads();  // constants + resident filters visible
     }
-    __syncthreads();  // constants + resident filters visible
     STAMP(4);
 
     f32x4 acc[MT][NTW];
@@ -350,11 +363,16 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
     // element index (times Co) of this lane's output pixel in pixel tile mi of the tile at (vr0, c0); pok = inside the image
     auto out_pixel = [&](int vr0, int c0, int mi, bool& pok) __attribute__((always_inline)) -> size_t {
         const int eb0 = sdiv(vr0, k.m_vp), ey0 = vr0 - eb0 * vpitch;
-        const int ty = e_yx[mi] >> 16, tx = e_yx[mi] & 0xffff;
+        int eyx = e_yx[mi];
+        if constexpr (DB) {   // not kept in registers across the stage loop
+            const int m = (wm * MT + mi) * 16 + r16, ty_ = fdiv(m, k.r_TW);
+            eyx = m < tilepx ? ((ty_ << 16) | (m - ty_ * k.TW)) : -1;
+        }
+        const int ty = eyx >> 16, tx = eyx & 0xffff;
         const int oy0 = ey0 + ty, c = c0 + tx;
         const int wr_ = fdiv(oy0, k.r_vp);
         const int oy = mad24_vsv(wr_, -vpitch, oy0), b = eb0 + wr_;
-        pok = (e_yx[mi] >= 0) & (b < p.B) & (oy < p.Ho) & (c < p.Wo);
+        pok = (eyx >= 0) & (b < p.B) & (oy < p.Ho) & (c < p.Wo);
         const int e = mulu24_vs(madu24_vsv(madu24_vsv(b, p.Ho, oy), p.Wo, c), p.Co);
         return pok ? (size_t)(uint32_t)e : 0;
     };
@@ -366,6 +384,134 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
         }
     };
 
+    if constexpr (DB) {
+        // ---- double-buffered image.  Registers hold stage s + 1 while stage s is multiplied; slot j (halo vector j, then
+        // filter vector j - NVA) is transformed + written into the OTHER image and immediately re-requested for stage s + 2
+        // behind the MFMAs of tap j, so every load has a whole stage to land and the barrier at the end of the stage is
+        // the only one: it publishes image (s + 1) and retires image (s).
+        constexpr int NSLOT = NVA + NVB;
+        prefetch();                       // stage 0 -> registers
+        int cu_t = st_t, cu_ch = st_ch;
+        bool cu_have = st_have;
+        __syncthreads();                  // constants visible
+        write_lds(a_go, st_ch * CK);      // -> image 0
+        prefetch();                       // stage 1 -> registers
+        __syncthreads();
+        int img = 0;
+        while (cu_have) {
+            const int t = cu_t, ch0 = cu_ch;
+            const int tr = sdiv(t, k.m_tc), tc = t - tr * k.tiles_c;
+            const int vr0 = tr * k.TH, c0 = tc * k.TW;
+            const bool last_chunk = (ch0 + 1 == k.nchunks);
+            bool pokv[EPRE ? MT : 1];
+            size_t pixv[EPRE ? MT : 1];
+            EpiRaw<NTW> er[EPRE ? MT : 1];
+            // the stage in the registers (to be written) and the stage to request
+            const int k0w = st_ch * CK, k0n = ch_n * CK;
+            const bool en_n = have_n, nt = have_n && ch_n == 0;
+            int y0n = 0, cbn = 0, b0n = 0;
+            if (nt) tile_terms(t_n, y0n, cbn, b0n);
+            const char* sAr = sA + img * k.sz_a;
+            const char* sBr = sB + img * k.sz_b;
+            char* sAw = sA + (img ^ 1) * k.sz_a;
+            char* sBw = sB + (img ^ 1) * k.sz_b;
+            auto slot = [&](int j) __attribute__((always_inline)) {
+                if (j < NVA) {
+                    const int i = j;
+                    const int ch = k0w + a_part * KV;
+                    const bool ok = a_go[i] >= 0 && ch < p.Ci;
+                    const int chc = ok ? ch : 0;
+                    V16 val = ra[i];
+                    if (Q)
+                        val = xform_bnbwd<T, TY>(val, rq[i], cs + chc, cs + k.cipad + chc, cs + 2 * k.cipad + chc);
+                    else if (p.src.mode != STL_SRC_PLAIN)
+                        val = xform_bn<T>(val, cs + chc, cs + k.cipad + chc, relu_lo);
+                    mask16(val, ok);
+                    int v = tid + i * NTHR;
+                    asm volatile("" : "+v"(v));   // keeps the slot's address terms from being hoisted out of the stage loop (and spilled)
+                    if (v < k.HP * 4) *reinterpret_cast<V16*>(sAw + (v >> 2) * PSA + (v & 3) * 16) = val;
+                    if (nt) {   // a new tile (rare: these blocks mostly own one): the slot's halo position again, not kept in registers
+                        const int hp = v >> 2, hr = fdiv(hp, k.r_HC);
+                        a_go[i] = slot_go(v < k.HP * 4 ? ((hr << 16) | (hp - hr * k.HC)) : -1, y0n, cbn, b0n);
+                    }
+                    const bool chok = en_n && (k0n + a_part * KV) < p.Ci;
+                    const int off = (a_go[i] >= 0 && chok) ? a_go[i] + k0n : 0;
+                    ra[i] = ldg16((const char*)p.src.x + (size_t)(uint32_t)off * sizeof(T));
+                    if (Q) rq[i] = ldg16((const char*)p.src.y + (size_t)(uint32_t)off * sizeof(T));
+                } else {
+                    // filter vector v = (row n, tap, 16-byte part): LDS and global offsets from v itself (the b_g / b_l
+                    // registers of the single-image kernel do not fit beside the second tensor's staging registers)
+                    const int i = j - NVA;
+                    int v = tid + i * NTHR;
+                    asm volatile("" : "+v"(v));   // (as above)
+                    const int part = (v & 3) * KV;
+                    const int n = mulu24_vs(v, 1821) >> 16;   // v / 36 for v < 3311
+                    const bool vok = (i + 1) * NTHR <= BCO * TAPS * 4 || v < BCO * TAPS * 4;
+                    const bool rok = vok && n0 + n < p.Co;
+                    const int bg = madu24_vsv((v >> 2) + n0 * TAPS, p.Ci, part);
+                    V16 val = rb[i];
+                    mask16(val, rok && (k0w + part) < p.Ci);
+                    if (vok) *reinterpret_cast<V16*>(sBw + v * 16 + n * 32) = val;
+                    const bool okn = en_n && rok && (k0n + part) < p.Ci;
+                    rb[i] = ldg16((const char*)p.w + (size_t)(uint32_t)(okn ? bg + k0n : 0) * sizeof(T));
+                }
+            };
+            {
+                V16 wf[2][NTW], xf[2][MT];
+#pragma unroll
+                for (int ni = 0; ni < NTW; ++ni) wf[0][ni] = *reinterpret_cast<const V16*>(sBr + woff + ni * 16 * ROWB);
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) xf[0][mi] = *reinterpret_cast<const V16*>(sAr + xoff[mi]);
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap) {
+                    if (tap + 1 < TAPS) {
+                        const int toff = (((tap + 1) / KS) * k.HC + ((tap + 1) % KS)) * PSA;
+#pragma unroll
+                        for (int ni = 0; ni < NTW; ++ni)
+                            wf[(tap + 1) & 1][ni] = *reinterpret_cast<const V16*>(sBr + woff + ni * 16 * ROWB + (tap + 1) * 64);
+#pragma unroll
+                        for (int mi = 0; mi < MT; ++mi) xf[(tap + 1) & 1][mi] = *reinterpret_cast<const V16*>(sAr + xoff[mi] + toff);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NTW; ++ni) mma16<T>(acc[mi][ni], wf[tap & 1][ni], xf[tap & 1][mi]);
+#pragma unroll
+                    for (int j = tap; j < NSLOT; j += TAPS) slot(j);
+                    if constexpr (EPRE) {
+                        // epilogue operands of the tile: requested behind the last halo slot (whose transform temporaries
+                        // and these 48 registers do not fit side by side), six taps ahead of their use
+                        if (tap == (NVA < TAPS ? NVA : TAPS - 1) && last_chunk) epi_fetch(vr0, c0, pokv, pixv, er);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // stage s + 1 becomes the current one, the requested stage is the one in the registers; advance the cursor
+            cu_t = st_t, cu_ch = st_ch, cu_have = st_have;
+            st_t = t_n, st_ch = ch_n, st_have = have_n;
+            if (++ch_n == k.nchunks) {
+                ch_n = 0, it_n += nx, t_n = xcd * T8 + it_n;
+                have_n = have_n && (it_n < T8) && (t_n < k.npt);
+            }
+            __syncthreads();  // image (s + 1) complete, image (s) free
+            img ^= 1;
+            if (last_chunk) {
+                if constexpr (EPRE) {
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi)
+                        epilogue_apply<T, NTW, BCO, false, TY>(p, acc[mi], cm, pokv[mi], pixv[mi], n0, wn * NTW * 16, g, s0, s1, er[mi]);
+                } else {
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi) {
+                        bool pok;
+                        const size_t pix = out_pixel(vr0, c0, mi, pok);
+                        epilogue_tile<T, NTW, BCO, PE, TY>(p, acc[mi], cm, pok, pix, n0, wn * NTW * 16, g, s0, s1);
+                    }
+                }
+            }
+        }
+    } else
     // flat loop over stages (tile, chunk); exactly ONE issue() site inside the loop so that the staging registers need
     // no PHI copies (which would force a vmcnt(0) before the MFMAs)
     while (st_have) {
@@ -468,17 +614,17 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 #include "conv_ws.inc"
 #include "conv1x1.inc"
 
-template <typename T, typename TY, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, bool PE, int OCC = 1, int WR = -1, bool ZM = false>
+template <typename T, typename TY, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, bool PE, int OCC = 1, int WR = -1, bool ZM = false, bool DB = false>
 int launch(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM, TY>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM, TY, DB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    STL_LAUNCH((conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM, TY>), grid, dim3(64 * WM * WN), lds, st, k);
+    STL_LAUNCH((conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM, TY, DB>), grid, dim3(64 * WM * WN), lds, st, k);
     static char nbuf[160];
-    static const char* nm = stl_kname<T>(nbuf, "conv_core_kernel", {KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM, stl_code<TY>()});
+    static const char* nm = stl_kname<T>(nbuf, "conv_core_kernel", {KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM, stl_code<TY>(), DB});
     stl_note_kernel(nm, true);
     STL_LAUNCH_CHECK("conv_core");
     return 0;
@@ -488,20 +634,21 @@ int launch(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
 //   0 = 128 x 64, 4 waves  -- small maps where no 256-pixel tile fits, and explicit 128-pixel tiles (tests)
 //   1 = 512 x 32, 8 waves  -- Co <= 32 with >= 128 input channels on a large map (transition1 256 -> 32: each filter chunk staged
 //                             once per 512 pixels instead of once per 128: 105.8 -> 71.8 us)
-//   2 = 256 x 64, 8 waves  -- the C >= 64 3x3 layers (forward and data gradient)
+//   2 = 256 x 64, 8 waves  -- C >= 64 layers whose K is one chunk, 1x1 convolutions on that block, the block-end (BNADD) source
+//   3 = 256 x 64, 8 waves, two LDS images, one barrier per stage -- the C >= 64 3x3 layers (forward and data gradient; round 4)
 //   4 = 128 x 32, 4 waves  -- C <= 32 fallback where no 256-pixel tile fits (<= 128 VGPRs, <= 40 KB LDS: four blocks per CU)
 //   7 = 128 x 64, wave-specialised (4 loader + 4 compute waves, double-buffered LDS image) -- stride-2 convolutions
 //   8 = 256 x 32, 8 waves  -- the C <= 32 3x3 layers (two 128-pixel halves share one filter copy and one halo tile)
 //   9 = 128 x 32, wave-specialised -- the deep small maps (Co >= 256 on <= 16384 pixels: 12x9 at C = 256 gets 256 blocks, not 128)
-// (3 = 256 x 128 and 5 / 6 = wave-specialised 512 x 32 / 256 x 64 lost end to end in rounds 2 and 3 and were removed.)
+// (256 x 128 and the wave-specialised 512 x 32 / 256 x 64 blocks -- ids 5 / 6 -- lost end to end in rounds 2 and 3 and were removed.)
 struct Shape {
     int px, co, thr;   // pixels / output channels per block, threads
-    int ws;            // 1: wave-specialised kernel (4 loader + 4 compute waves, double-buffered LDS)
+    int ws;            // 1: wave-specialised kernel (4 loader + 4 compute waves, double-buffered LDS); 2: uniform kernel, two LDS images
     int lthr, nva_max; // threads that stage the halo, max staging vectors per such thread
 };
 constexpr int NSHAPES = 10;
 constexpr Shape SHAPES[NSHAPES] = {{128, 64, 256, 0, 256, 9}, {512, 32, 512, 0, 512, 6}, {256, 64, 512, 0, 512, 3},
-                                   {0, 0, 0, 0, 1, 0}, {128, 32, 256, 0, 256, 6},
+                                   {256, 64, 512, 2, 512, 3}, {128, 32, 256, 0, 256, 6},
                                    {0, 0, 0, 0, 1, 0}, {0, 0, 0, 0, 1, 0}, {128, 64, 512, 1, 256, 9},
                                    {256, 32, 512, 0, 512, 3}, {128, 32, 512, 1, 256, 3}};
 
@@ -518,6 +665,11 @@ int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStrea
         case 2:   // the data-gradient form is sized for one block per CU (up to 256 VGPRs): a register cap alone spills
                   // (168 / 128 VGPRs: 49 / 160 spilled registers, 15.6 / 18.2 vs 14.64 ms per step in round 3)
             if (nva <= 3) return launch<T, TY, KS, 4, 2, 4, 2, 3, Q, PE, 1>(k, grid, lds, st);
+            break;
+        case 3:
+            if constexpr (KS == 3) {
+                if (nva <= 3 && !k.wres) return launch<T, TY, KS, 4, 2, 4, 2, 3, Q, PE, 1, 0, false, true>(k, grid, lds, st);
+            }
             break;
         case 8:   // three (data gradient) resp. four waves per SIMD, no spills
             if (nva <= 3 && k.wres) return launch<T, TY, KS, 8, 1, 2, 2, 3, Q, PE, 4, 1>(k, grid, lds, st);
@@ -542,12 +694,13 @@ int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStrea
 // block-end source (STL_SRC_BNADD): the shapes the two-conv units of the network are planned with -- 256 px x 32 co
 // (C <= 32), 256 px x 64 co (C = 64 / 128) and their small-map fallbacks; own instantiations, so that the
 // data-gradient kernels (Q without ZM) carry none of this
-static bool bnadd_shape_ok(int shape, int nva) { return nva <= 3 && (shape == 0 || shape == 2 || shape == 4 || shape == 8); }
+static bool bnadd_shape_ok(int shape, int nva) { return nva <= 3 && (shape == 0 || shape == 2 || shape == 3 || shape == 4 || shape == 8); }
 template <typename T>
 int dispatch_bnadd(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     if (nva <= 3) switch (shape) {
         case 0: return launch<T, T, 3, 4, 1, 2, 4, 3, true, true, 1, -1, true>(k, grid, lds, st);
-        case 2: return launch<T, T, 3, 4, 2, 4, 2, 3, true, true, 1, -1, true>(k, grid, lds, st);
+        case 2:
+        case 3: return launch<T, T, 3, 4, 2, 4, 2, 3, true, true, 1, -1, true>(k, grid, lds, st);   // (shape 3: image 0 of its layout)
         case 4: return launch<T, T, 3, 4, 1, 2, 2, 3, true, true, 3, -1, true>(k, grid, lds, st);
         case 8: return launch<T, T, 3, 8, 1, 2, 2, 3, true, true, 3, -1, true>(k, grid, lds, st);
     }
@@ -604,7 +757,7 @@ size_t lds_bytes(const stl_conv& p, int shape, int TH, int TW, int ck, ConvK* ou
     const int off_b = off;
     const int sz_b = bco * (taps * 64 + 32);
     // wave-specialised kernel: keep the whole filter slab (all chunks) resident when it fits
-    const bool resident = nchunks == 1 || (ws && (size_t)off + (size_t)sz_b * nchunks <= 150 * 1024);
+    const bool resident = nchunks == 1 || (ws == 1 && (size_t)off + (size_t)sz_b * nchunks <= 150 * 1024);
     off += resident ? sz_b * nchunks : sz_b * (ws ? 2 : 1);
     const int off_red = off_a;  // reused after the last stage
     const int red = 8 * 2 * bco * 4;
@@ -636,8 +789,15 @@ Plan choose_plan(const stl_conv& p, int ck) {
         const Shape sh = SHAPES[shape];
         if (sh.px == 0) continue;                    // retired shape ids
         if (sh.px > 128 && p.stride == 2) continue;  // stride-2 halos only fit the small blocks
-        if ((sh.ws != 0) != want_ws) continue;
+        if ((sh.ws == 1) != want_ws) continue;
         if (want_ws && shape != (deep_small ? 9 : 7)) continue;
+        // two LDS images (shape 3) wherever the 256 x 64 block walks K in more than one chunk: the staging of chunk c + 1
+        // hides behind the MFMAs of chunk c.  STL_CONV_DB=0: the single-image kernel everywhere (A/B).
+        if (shape == 2 || shape == 3) {
+            static const bool db_on = !(getenv("STL_CONV_DB") && atoi(getenv("STL_CONV_DB")) == 0);
+            const bool db = db_on && p.ks == 3 && p.stride == 1 && p.Ci > ck;
+            if ((shape == 3) != db) continue;
+        }
         if ((shape == 1 || shape == 8) && p.Co > 32) continue;
         if ((shape == 4 || shape == 8) && !c32) continue;
         if (c32 && shape != 4 && shape != 8) continue;

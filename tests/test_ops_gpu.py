@@ -211,6 +211,80 @@ def test_conv_bn_relu_chain_forward_backward(case, dt):
     assert relerr(dx0, ref) < tol * 3
 
 
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "mixed"])
+@pytest.mark.parametrize("case", [(4, 48, 36, 64, 64), (3, 24, 18, 128, 128), (2, 24, 18, 96, 72), (2, 24, 18, 64, 192)])
+def test_conv_two_image_block_equals_single_image(case, dt, monkeypatch):
+    """Block shape 3 (two LDS images, one barrier per stage, staging spread over the MFMA taps; round 4) against block
+    shape 2 (one image) on the same tile: same chunk and tap order, so outputs are BIT-identical -- forward with a
+    BN + ReLU source and the data gradient with BatchNorm-backward on load and every epilogue operand.  A 16-block grid
+    makes every block walk several tiles (the new-tile path of the staging slots)."""
+    code, td, tol = DT[dt]
+    fcode, ftd = FDT[dt]
+    ydt = fcode if fcode != code else 0
+    B, H, W, Ci, Co = case
+    monkeypatch.setenv("STL_CONV_GRID_CAP", "16")
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x0t = nhwc(torch.randn(B, Ci, H, W, device="cuda", generator=g) * 1.5 + 0.3, ftd)
+    wt = (torch.randn(Co, 3, 3, Ci, device="cuda", generator=g) / math.sqrt(9 * Ci)).to(ftd)
+    g1, b1 = torch.rand(Ci, device="cuda", generator=g) + 0.5, torch.rand(Ci, device="cuda", generator=g) - 0.5
+    g2 = torch.rand(Co, device="cuda", generator=g) + 0.5
+    st1 = stats_of(x0t, Ci)
+
+    def forward(shape):
+        yk = torch.full((B * H * W * Co,), float("nan"), device="cuda", dtype=ftd)
+        st2 = torch.zeros(capi.NSHARD * 2 * Co, dtype=torch.float64, device="cuda")
+        p = capi.Conv()
+        p.dtype, p.B, p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.Co, p.ks, p.stride = fcode, B, H, W, Ci, H, W, Co, 3, 1
+        p.TH, p.TW, p.shape = 0, 0, -1
+        p.src = bn_src(x0t, st1, g1, b1, B * H * W, True)
+        p.w, p.out, p.out_stats = wt.data_ptr(), yk.data_ptr(), st2.data_ptr()
+        capi.call("stl_conv_plan", C.byref(p))
+        assert p.shape == 3, f"planner chose block shape {p.shape}"
+        p.shape = shape
+        capi.call("stl_conv_forward", C.byref(p), stream())
+        torch.cuda.synchronize()
+        return yk, st2, p
+    y3, s3, p3 = forward(3)
+    y2, s2, _ = forward(2)
+    assert not torch.isnan(y3.float()).any()
+    assert torch.equal(y3, y2)
+    assert torch.allclose(s3, s2, rtol=1e-12, atol=1e-9)
+    # data gradient: BNBWD source (dt, y), addend, block-end mask, ReLU mask of the producing BN + its reductions
+    dtt = nhwc(torch.randn(B, Co, H, W, device="cuda", generator=g), td)
+    ykf, dtf = y3.view(-1, Co).double(), dtt.view(-1, Co).double()
+    mean2, rstd2 = ykf.mean(0), 1.0 / torch.sqrt(ykf.var(0, unbiased=False) + EPS)
+    rst2 = torch.zeros(capi.NSHARD, 2, Co, dtype=torch.float64, device="cuda")
+    rst2[0, 0], rst2[0, 1] = dtf.sum(0), (dtf * (ykf - mean2) * rstd2).sum(0)
+    gs = capi.Src()
+    gs.x, gs.y, gs.mode = dtt.data_ptr(), y3.data_ptr(), capi.SRC_BNBWD
+    gs.stats, gs.rstats, gs.gamma = s3.data_ptr(), rst2.data_ptr(), g2.data_ptr()
+    gs.inv_count, gs.eps = 1.0 / (B * H * W), EPS
+    wb = wt.float().view(Co, 9, Ci).flip(1).permute(2, 1, 0).contiguous().to(td)
+    addend = nhwc(torch.randn(B, Ci, H, W, device="cuda", generator=g), td)
+    zmask = nhwc(torch.randn(B, Ci, H, W, device="cuda", generator=g), ftd)
+
+    def dgrad(shape):
+        dx = torch.full((B * H * W * Ci,), float("nan"), device="cuda", dtype=td)
+        red = torch.zeros(capi.NSHARD * 2 * Ci, dtype=torch.float64, device="cuda")
+        d = capi.Conv()
+        d.dtype, d.B, d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.Co, d.ks, d.stride, d.ydtype = code, B, H, W, Co, H, W, Ci, 3, 1, ydt
+        d.TH, d.TW, d.shape = 0, 0, -1
+        d.src, d.w, d.out = gs, wb.data_ptr(), dx.data_ptr()
+        d.mask_y, d.mask_bn, d.red = x0t.data_ptr(), p3.src, red.data_ptr()
+        d.addend, d.mask_z = addend.data_ptr(), zmask.data_ptr()
+        capi.call("stl_conv_plan", C.byref(d))
+        assert d.shape == 3, f"planner chose block shape {d.shape}"
+        d.shape = shape
+        capi.call("stl_conv_forward", C.byref(d), stream())
+        torch.cuda.synchronize()
+        return dx, red
+    dx3, r3 = dgrad(3)
+    dx2, r2 = dgrad(2)
+    assert not torch.isnan(dx3.float()).any()
+    assert torch.equal(dx3, dx2)
+    assert torch.allclose(r3, r2, rtol=1e-9, atol=1e-6)
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 def test_fuse_forward_backward_upsample(dt):
     code, td, tol = DT[dt]
