@@ -67,8 +67,13 @@ __device__ long long g_stamps2[64];  // wave-specialised kernel: [0..23] loader,
     do {                                                                  \
         if (k.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); \
     } while (0)
+#define STAMP2(i)                                                         \
+    do {                                                                  \
+        if (k.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && (i) < 64) g_stamps2[i] = wall_clock64(); \
+    } while (0)
 #else
 #define STAMP(i) do {} while (0)
+#define STAMP2(i) do {} while (0)
 #endif
 
 
@@ -112,7 +117,8 @@ __device__ __forceinline__ int sdiv(int n, unsigned long long m) { return (int)(
 // DB: two LDS images [halo | filters] (k.sz_a / k.sz_b apart) and ONE barrier per stage: while stage s is multiplied out of one
 // image, the staged registers of stage s + 1 are transformed and written into the other and the loads of stage s + 2 are
 // requested, one staging vector per tap of the MFMA loop (round 4; block shape 3).
-template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, bool PE, int OCC, int WR, bool ZM = false, typename TY = T, bool DB = false>
+// EO: compile-time set of epilogue operands of a data gradient, or -1 (conv_common.inc, EpiOps).
+template <typename T, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, bool PE, int OCC, int WR, bool ZM = false, typename TY = T, bool DB = false, int EO = -1>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const ConvK k) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTHR = 64 * WM * WN;
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
         if (c < p.Ci) src_consts(p.src, c, p.Ci, a, b, cc);
         cs[c] = a, cs[k.cipad + c] = b, cs[2 * k.cipad + c] = cc;
     }
-    if (!PE && p.mask_y) {
+    if (!PE && EpiOps<EO>::my(p)) {
         // the LAST wave computes the mask constants while the first one(s) do the source's: the two sets are
         // dependent global round trips each, and run in parallel on different waves instead of back to back
         for (int c = tid - (NTHR - 64); c >= 0 && c < BCO; c += 64) {
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
             pixv[mi] = out_pixel(vr0, c0, mi, pokv[mi]);
-            epilogue_fetch<T, NTW, true>(p, pokv[mi], pixv[mi], n0, wn * NTW * 16, g, er[mi]);
+            epilogue_fetch<T, NTW, true, EO>(p, pokv[mi], pixv[mi], n0, wn * NTW * 16, g, er[mi]);
         }
     };
 
@@ -398,7 +404,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
         prefetch();                       // stage 1 -> registers
         __syncthreads();
         int img = 0;
+        [[maybe_unused]] int dbg_it = 0;   // stamps: [4 i .. 4 i + 3] = top of stage i, taps done, barrier passed, epilogue done
         while (cu_have) {
+            STAMP2(4 * dbg_it);
             const int t = cu_t, ch0 = cu_ch;
             const int tr = sdiv(t, k.m_tc), tc = t - tr * k.tiles_c;
             const int vr0 = tr * k.TH, c0 = tc * k.TW;
@@ -494,22 +502,29 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
                 ch_n = 0, it_n += nx, t_n = xcd * T8 + it_n;
                 have_n = have_n && (it_n < T8) && (t_n < k.npt);
             }
+            STAMP2(4 * dbg_it + 1);
             __syncthreads();  // image (s + 1) complete, image (s) free
+            STAMP2(4 * dbg_it + 2);
             img ^= 1;
             if (last_chunk) {
                 if constexpr (EPRE) {
 #pragma unroll
                     for (int mi = 0; mi < MT; ++mi)
-                        epilogue_apply<T, NTW, BCO, false, TY>(p, acc[mi], cm, pokv[mi], pixv[mi], n0, wn * NTW * 16, g, s0, s1, er[mi]);
+                        epilogue_apply<T, NTW, BCO, false, TY, EO>(p, acc[mi], cm, pokv[mi], pixv[mi], n0, wn * NTW * 16, g, s0, s1, er[mi]);
                 } else {
 #pragma unroll
                     for (int mi = 0; mi < MT; ++mi) {
                         bool pok;
                         const size_t pix = out_pixel(vr0, c0, mi, pok);
-                        epilogue_tile<T, NTW, BCO, PE, TY>(p, acc[mi], cm, pok, pix, n0, wn * NTW * 16, g, s0, s1);
+                        epilogue_tile<T, NTW, BCO, PE, TY, EO>(p, acc[mi], cm, pok, pix, n0, wn * NTW * 16, g, s0, s1);
+                        if constexpr (EO >= 0) __builtin_amdgcn_sched_barrier(0);   // tile by tile: interleaved, the tiles spill at 128 registers
                     }
                 }
             }
+            STAMP2(4 * dbg_it + 3);
+#ifdef STL_STAMPS
+            ++dbg_it;
+#endif
         }
     } else
     // flat loop over stages (tile, chunk); exactly ONE issue() site inside the loop so that the staging registers need
@@ -565,13 +580,14 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
             if constexpr (EPRE) {
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
-                    epilogue_apply<T, NTW, BCO, false, TY>(p, acc[mi], cm, pokv[mi], pixv[mi], n0, wn * NTW * 16, g, s0, s1, er[mi]);
+                    epilogue_apply<T, NTW, BCO, false, TY, EO>(p, acc[mi], cm, pokv[mi], pixv[mi], n0, wn * NTW * 16, g, s0, s1, er[mi]);
             } else {   // register-tight instantiations: tile by tile
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) {
                     bool pok;
                     const size_t pix = out_pixel(vr0, c0, mi, pok);
-                    epilogue_tile<T, NTW, BCO, PE, TY>(p, acc[mi], cm, pok, pix, n0, wn * NTW * 16, g, s0, s1);
+                    epilogue_tile<T, NTW, BCO, PE, TY, EO>(p, acc[mi], cm, pok, pix, n0, wn * NTW * 16, g, s0, s1);
+                    if constexpr (EO >= 0) __builtin_amdgcn_sched_barrier(0);   // tile by tile: interleaved, the tiles spill at 128 registers
                 }
             }
         }
@@ -614,17 +630,17 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 #include "conv_ws.inc"
 #include "conv1x1.inc"
 
-template <typename T, typename TY, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, bool PE, int OCC = 1, int WR = -1, bool ZM = false, bool DB = false>
+template <typename T, typename TY, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, bool PE, int OCC = 1, int WR = -1, bool ZM = false, bool DB = false, int EO = -1>
 int launch(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM, TY, DB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM, TY, DB, EO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    STL_LAUNCH((conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM, TY, DB>), grid, dim3(64 * WM * WN), lds, st, k);
+    STL_LAUNCH((conv_core_kernel<T, KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM, TY, DB, EO>), grid, dim3(64 * WM * WN), lds, st, k);
     static char nbuf[160];
-    static const char* nm = stl_kname<T>(nbuf, "conv_core_kernel", {KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM, stl_code<TY>(), DB});
+    static const char* nm = stl_kname<T>(nbuf, "conv_core_kernel", {KS, WM, WN, MT, NTW, NVA, Q, PE, OCC, WR, ZM, stl_code<TY>(), DB, EO});
     stl_note_kernel(nm, true);
     STL_LAUNCH_CHECK("conv_core");
     return 0;
@@ -652,7 +668,9 @@ constexpr Shape SHAPES[NSHAPES] = {{128, 64, 256, 0, 256, 9}, {512, 32, 512, 0, 
                                    {0, 0, 0, 0, 1, 0}, {0, 0, 0, 0, 1, 0}, {128, 64, 512, 1, 256, 9},
                                    {256, 32, 512, 0, 512, 3}, {128, 32, 512, 1, 256, 3}};
 
-template <typename T, typename TY, int KS, bool Q, bool PE>
+// EO >= 0 (data gradients whose operand set the planner emits in bulk): own instantiations of the C >= 64 3x3 block (the
+// C <= 32 block at its 128-register budget spills 6 - 12 registers once the compiler may interleave the tiles)
+template <typename T, typename TY, int KS, bool Q, bool PE, int EO = -1>
 int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     switch (shape) {
         case 0:
@@ -668,11 +686,11 @@ int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStrea
             break;
         case 3:
             if constexpr (KS == 3) {
-                if (nva <= 3 && !k.wres) return launch<T, TY, KS, 4, 2, 4, 2, 3, Q, PE, 1, 0, false, true>(k, grid, lds, st);
+                if (nva <= 3 && !k.wres) return launch<T, TY, KS, 4, 2, 4, 2, 3, Q, PE, 1, 0, false, true, EO>(k, grid, lds, st);
             }
             break;
         case 8:   // three (data gradient) resp. four waves per SIMD, no spills
-            if (nva <= 3 && k.wres) return launch<T, TY, KS, 8, 1, 2, 2, 3, Q, PE, 4, 1>(k, grid, lds, st);
+            if (nva <= 3 && k.wres) return launch<T, TY, KS, 8, 1, 2, 2, 3, Q, PE, 4, 1, false, false, (KS == 3 ? EO : -1)>(k, grid, lds, st);
             if (nva <= 3) return launch<T, TY, KS, 8, 1, 2, 2, 3, Q, PE, (Q ? 3 : 4)>(k, grid, lds, st);
             break;
         case 4:
@@ -724,7 +742,13 @@ int conv_backend(int path, const stl_conv& p, const ConvK& k, int shape, int nva
     const bool plain = !p.bias && !p.addend && !p.mask_y && !p.mask_z && !p.red;   // forward convs of the pose network
     if (p.ks == 3) {
         if (q) {
-            if constexpr (BWD) return dispatch<T, TY, 3, true, false>(shape, nva, k, grid, lds, st);
+            if constexpr (BWD) {
+                const int eo = (p.mask_y ? 1 : 0) | (p.addend ? 2 : 0) | (p.mask_z ? 4 : 0);
+                const bool spec = (shape == 3 || (shape == 8 && k.wres)) && !getenv("STL_CONV_NO_EO") && !p.bias && !p.out_relu && !p.out_stats && (p.red != nullptr) == (p.mask_y != nullptr);
+                if (spec && eo == 1) return dispatch<T, TY, 3, true, false, 1>(shape, nva, k, grid, lds, st);
+                if (spec && eo == 7) return dispatch<T, TY, 3, true, false, 7>(shape, nva, k, grid, lds, st);
+                return dispatch<T, TY, 3, true, false>(shape, nva, k, grid, lds, st);
+            }
         }
         if constexpr (FWD) return plain ? dispatch<T, T, 3, false, true>(shape, nva, k, grid, lds, st) : dispatch<T, T, 3, false, false>(shape, nva, k, grid, lds, st);
     }
