@@ -672,6 +672,8 @@ constexpr Shape SHAPES[NSHAPES] = {{128, 64, 256, 0, 256, 9}, {512, 32, 512, 0, 
 // C <= 32 block at its 128-register budget spills 6 - 12 registers once the compiler may interleave the tiles)
 template <typename T, typename TY, int KS, bool Q, bool PE, int EO = -1>
 int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+    constexpr int EOC = (Q && KS == 3) ? EO : -1;   // conv_core: data gradients only (its forward convs have the plain epilogue)
+    constexpr int EOW = KS == 3 ? EO : -1;          // wave-specialised kernel: forward (EO 8) and data gradients
     switch (shape) {
         case 0:
             if (nva <= 3) return launch<T, TY, KS, 4, 1, 2, 4, 3, Q, PE>(k, grid, lds, st);
@@ -686,11 +688,11 @@ int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStrea
             break;
         case 3:
             if constexpr (KS == 3) {
-                if (nva <= 3 && !k.wres) return launch<T, TY, KS, 4, 2, 4, 2, 3, Q, PE, 1, 0, false, true, EO>(k, grid, lds, st);
+                if (nva <= 3 && !k.wres) return launch<T, TY, KS, 4, 2, 4, 2, 3, Q, PE, 1, 0, false, true, EOC>(k, grid, lds, st);
             }
             break;
         case 8:   // three (data gradient) resp. four waves per SIMD, no spills
-            if (nva <= 3 && k.wres) return launch<T, TY, KS, 8, 1, 2, 2, 3, Q, PE, 4, 1, false, false, (KS == 3 ? EO : -1)>(k, grid, lds, st);
+            if (nva <= 3 && k.wres) return launch<T, TY, KS, 8, 1, 2, 2, 3, Q, PE, 4, 1, false, false, EOC>(k, grid, lds, st);
             if (nva <= 3) return launch<T, TY, KS, 8, 1, 2, 2, 3, Q, PE, (Q ? 3 : 4)>(k, grid, lds, st);
             break;
         case 4:
@@ -699,11 +701,11 @@ int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStrea
             if (nva <= 6) return launch<T, TY, KS, 4, 1, 2, 2, 6, Q, PE, 3>(k, grid, lds, st);
             break;
         case 7:
-            if (nva <= 3) return launch_ws<T, TY, KS, 2, 4, 3, Q>(k, grid, lds, st);
-            if (nva <= 9) return launch_ws<T, TY, KS, 2, 4, 9, Q>(k, grid, lds, st);
+            if (nva <= 3) return launch_ws<T, TY, KS, 2, 4, 3, Q, (Q ? -1 : EOW)>(k, grid, lds, st);   // (no stride-2 data gradient uses it)
+            if (nva <= 9) return launch_ws<T, TY, KS, 2, 4, 9, Q, (Q ? -1 : EOW)>(k, grid, lds, st);
             break;
         case 9:
-            if (nva <= 3) return launch_ws<T, TY, KS, 2, 2, 3, Q>(k, grid, lds, st);
+            if (nva <= 3) return launch_ws<T, TY, KS, 2, 2, 3, Q, EOW>(k, grid, lds, st);
             break;
     }
     return stl_set_error("conv: no kernel variant for block shape %d with %d staging vectors per thread", shape, nva);
@@ -740,17 +742,23 @@ int conv_backend(int path, const stl_conv& p, const ConvK& k, int shape, int nva
         if constexpr (FWD) return dispatch_bnadd<T>(shape, nva, k, grid, lds, st);
     }
     const bool plain = !p.bias && !p.addend && !p.mask_y && !p.mask_z && !p.red;   // forward convs of the pose network
+    // compile-time epilogue operand set where the launch matches one of the planner's forms (STL_CONV_NO_EO=1: never -- A/B)
+    const char* noeo = getenv("STL_CONV_NO_EO");   // bit 0: conv_core / conv_ws, bit 1: conv1x1
+    const int eo = (noeo && (atoi(noeo) & 1)) ? -1 : epi_code(p);
     if (p.ks == 3) {
         if (q) {
             if constexpr (BWD) {
-                const int eo = (p.mask_y ? 1 : 0) | (p.addend ? 2 : 0) | (p.mask_z ? 4 : 0);
-                const bool spec = (shape == 3 || (shape == 8 && k.wres)) && !getenv("STL_CONV_NO_EO") && !p.bias && !p.out_relu && !p.out_stats && (p.red != nullptr) == (p.mask_y != nullptr);
-                if (spec && eo == 1) return dispatch<T, TY, 3, true, false, 1>(shape, nva, k, grid, lds, st);
-                if (spec && eo == 7) return dispatch<T, TY, 3, true, false, 7>(shape, nva, k, grid, lds, st);
+                if (eo == 1) return dispatch<T, TY, 3, true, false, 1>(shape, nva, k, grid, lds, st);
+                if (eo == 7) return dispatch<T, TY, 3, true, false, 7>(shape, nva, k, grid, lds, st);
+                if (eo == 2) return dispatch<T, TY, 3, true, false, 2>(shape, nva, k, grid, lds, st);
+                if (eo == 0) return dispatch<T, TY, 3, true, false, 0>(shape, nva, k, grid, lds, st);
                 return dispatch<T, TY, 3, true, false>(shape, nva, k, grid, lds, st);
             }
         }
-        if constexpr (FWD) return plain ? dispatch<T, T, 3, false, true>(shape, nva, k, grid, lds, st) : dispatch<T, T, 3, false, false>(shape, nva, k, grid, lds, st);
+        if constexpr (FWD) {
+            if (plain && eo == 8) return dispatch<T, T, 3, false, true, 8>(shape, nva, k, grid, lds, st);
+            return plain ? dispatch<T, T, 3, false, true>(shape, nva, k, grid, lds, st) : dispatch<T, T, 3, false, false>(shape, nva, k, grid, lds, st);
+        }
     }
     if (q) {
         if constexpr (BWD) return dispatch<T, TY, 1, true, false>(shape, nva, k, grid, lds, st);
