@@ -286,6 +286,77 @@ def test_conv_two_image_block_equals_single_image(case, dt, monkeypatch):
     assert torch.allclose(r3, r2, rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "mixed", "fp32"])
+@pytest.mark.parametrize("ops", ["my", "my+ad+mz", "ad", "none"])
+@pytest.mark.parametrize("case", [(4, 48, 36, 32, 32, 3), (2, 12, 9, 256, 256, 3), (2, 24, 18, 64, 256, 1), (4, 24, 18, 128, 64, 3)])
+def test_conv_compile_time_epilogue_sets_equal_runtime_form(case, ops, dt, monkeypatch):
+    """The data-gradient kernels specialised for an epilogue operand set (EO: mask_y + reductions / all three / addend only /
+    none; round 4) against the same launch through the run-time-checked epilogue (STL_CONV_NO_EO=3): bit-identical dx; the
+    forward conv with statistics (EO 8) likewise.  Cases: C <= 32 block, wave-specialised 128 x 32 block, 1x1 kernel, C >= 64 block."""
+    code, td, tol = DT[dt]
+    fcode, ftd = FDT[dt]
+    ydt = fcode if fcode != code else 0
+    B, H, W, Ci, Co, ks = case
+    g = torch.Generator(device="cuda").manual_seed(12)
+    x0t = nhwc(torch.randn(B, Ci, H, W, device="cuda", generator=g) * 1.5 + 0.3, ftd)
+    wt = (torch.randn(Co, ks, ks, Ci, device="cuda", generator=g) / math.sqrt(ks * ks * Ci)).to(ftd)
+    g1, b1 = torch.rand(Ci, device="cuda", generator=g) + 0.5, torch.rand(Ci, device="cuda", generator=g) - 0.5
+    g2 = torch.rand(Co, device="cuda", generator=g) + 0.5
+    st1 = stats_of(x0t, Ci)
+    src1 = bn_src(x0t, st1, g1, b1, B * H * W, True)
+
+    def forward():
+        yk = torch.full((B * H * W * Co,), float("nan"), device="cuda", dtype=ftd)
+        st2 = torch.zeros(capi.NSHARD * 2 * Co, dtype=torch.float64, device="cuda")
+        p = capi.Conv()
+        p.dtype, p.B, p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.Co, p.ks, p.stride = fcode, B, H, W, Ci, H, W, Co, ks, 1
+        p.TH, p.TW, p.shape = 0, 0, -1
+        p.src, p.w, p.out, p.out_stats = src1, wt.data_ptr(), yk.data_ptr(), st2.data_ptr()
+        capi.call("stl_conv_forward", C.byref(p), stream())
+        torch.cuda.synchronize()
+        return yk, st2
+    ya, sa = forward()
+    monkeypatch.setenv("STL_CONV_NO_EO", "3")
+    yb, sb = forward()
+    monkeypatch.delenv("STL_CONV_NO_EO")
+    assert not torch.isnan(ya.float()).any() and torch.equal(ya, yb)
+    assert torch.allclose(sa, sb, rtol=1e-5, atol=1e-3)
+    dtt = nhwc(torch.randn(B, Co, H, W, device="cuda", generator=g), td)
+    ykf, dtf = ya.view(-1, Co).double(), dtt.view(-1, Co).double()
+    mean2, rstd2 = ykf.mean(0), 1.0 / torch.sqrt(ykf.var(0, unbiased=False) + EPS)
+    rst2 = torch.zeros(capi.NSHARD, 2, Co, dtype=torch.float64, device="cuda")
+    rst2[0, 0], rst2[0, 1] = dtf.sum(0), (dtf * (ykf - mean2) * rstd2).sum(0)
+    gs = capi.Src()
+    gs.x, gs.y, gs.mode = dtt.data_ptr(), ya.data_ptr(), capi.SRC_BNBWD
+    gs.stats, gs.rstats, gs.gamma = sa.data_ptr(), rst2.data_ptr(), g2.data_ptr()
+    gs.inv_count, gs.eps = 1.0 / (B * H * W), EPS
+    wb = wt.float().view(Co, ks * ks, Ci).flip(1).permute(2, 1, 0).contiguous().to(td)
+    addend = nhwc(torch.randn(B, Ci, H, W, device="cuda", generator=g), td)
+    zmask = nhwc(torch.randn(B, Ci, H, W, device="cuda", generator=g), ftd)
+
+    def dgrad():
+        dx = torch.full((B * H * W * Ci,), float("nan"), device="cuda", dtype=td)
+        red = torch.zeros(capi.NSHARD * 2 * Ci, dtype=torch.float64, device="cuda")
+        d = capi.Conv()
+        d.dtype, d.B, d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.Co, d.ks, d.stride, d.ydtype = code, B, H, W, Co, H, W, Ci, ks, 1, ydt
+        d.TH, d.TW, d.shape = 0, 0, -1
+        d.src, d.w, d.out = gs, wb.data_ptr(), dx.data_ptr()
+        if "my" in ops:
+            d.mask_y, d.mask_bn, d.red = x0t.data_ptr(), bn_src(x0t, st1, g1, b1, B * H * W, "mz" not in ops), red.data_ptr()
+        if "ad" in ops:
+            d.addend = addend.data_ptr()
+        if "mz" in ops:
+            d.mask_z = zmask.data_ptr()
+        capi.call("stl_conv_forward", C.byref(d), stream())
+        torch.cuda.synchronize()
+        return dx, red
+    dxa, ra = dgrad()
+    monkeypatch.setenv("STL_CONV_NO_EO", "3")
+    dxb, rb = dgrad()
+    assert not torch.isnan(dxa.float()).any() and torch.equal(dxa, dxb)
+    assert torch.allclose(ra, rb, rtol=1e-5, atol=1e-3)
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 def test_fuse_forward_backward_upsample(dt):
     code, td, tol = DT[dt]
