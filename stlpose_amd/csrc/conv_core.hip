@@ -423,6 +423,21 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
             const bool en_n = have_n, nt = have_n && ch_n == 0;
             int y0n = 0, cbn = 0, b0n = 0;
             if (nt) tile_terms(t_n, y0n, cbn, b0n);
+            // channel constants of the stage in the registers (this thread's KV channels of the chunk: the same for all its
+            // halo slots); live over the halo slots only
+            // (not beside the 48 operand registers of the three-operand data gradient: 11 - 19 spilled registers)
+            constexpr bool KREG = !Q || EO == 0 || EO == 1 || EO == 2;
+            constexpr int NPK = sizeof(T) == 2 ? 4 : 2;
+            f2v kca[NPK], kcb[NPK], kcc[Q ? NPK : 1];
+            if constexpr (KREG) {
+                const int ch = k0w + a_part * KV;   // < cipad: the tables cover it
+#pragma unroll
+                for (int i = 0; i < NPK; ++i) {
+                    kca[i] = reinterpret_cast<const f2v*>(cs + ch)[i];
+                    kcb[i] = reinterpret_cast<const f2v*>(cs + k.cipad + ch)[i];
+                    if (Q) kcc[i] = reinterpret_cast<const f2v*>(cs + 2 * k.cipad + ch)[i];
+                }
+            }
             const char* sAr = sA + img * k.sz_a;
             const char* sBr = sB + img * k.sz_b;
             char* sAw = sA + (img ^ 1) * k.sz_a;
@@ -432,12 +447,15 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
                     const int i = j;
                     const int ch = k0w + a_part * KV;
                     const bool ok = a_go[i] >= 0 && ch < p.Ci;
-                    const int chc = ok ? ch : 0;
                     V16 val = ra[i];
-                    if (Q)
-                        val = xform_bnbwd<T, TY>(val, rq[i], cs + chc, cs + k.cipad + chc, cs + 2 * k.cipad + chc);
-                    else if (p.src.mode != STL_SRC_PLAIN)
-                        val = xform_bn<T>(val, cs + chc, cs + k.cipad + chc, relu_lo);
+                    if constexpr (KREG) {
+                        if (Q)
+                            val = xform_bnbwd_r<T, TY>(val, rq[i], kca, kcb, kcc);
+                        else if (p.src.mode != STL_SRC_PLAIN)
+                            val = xform_bn_r<T>(val, kca, kcb, relu_lo);
+                    } else {
+                        val = xform_bnbwd<T, TY>(val, rq[i], cs + ch, cs + k.cipad + ch, cs + 2 * k.cipad + ch);
+                    }
                     mask16(val, ok);
                     int v = tid + i * NTHR;
                     asm volatile("" : "+v"(v));   // keeps the slot's address terms from being hoisted out of the stage loop (and spilled)
