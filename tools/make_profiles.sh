@@ -39,3 +39,11 @@ python $ROOT/tools/alone_time.py $OUT/${R}_trace_default.csv.gz > $OUT/${R}_alon
 rm -rf $OUT/trace_default $OUT/trace_serial $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/trace_dp
 ls -la $OUT
 echo profiles done
+# 6. (optional: `make_profiles.sh r04 sq`) SQ wave-state counters per kernel family: parked / issue-stalled / issuing share of the wave cycles
+if [ "$2" = "sq" ]; then
+  timeout -k 10 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_sq -- $B --steps 2 --warmup 1 > $OUT/pmc_sq.log 2>&1 || echo "sq pass 1 failed"
+  timeout -k 10 400 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- $B --steps 2 --warmup 1 > $OUT/pmc_sq2.log 2>&1 || echo "sq pass 2 failed"
+  python $ROOT/tools/pmc_sq.py $OUT/pmc_sq $OUT/pmc_sq2 > $OUT/${R}_sq_wave_states.txt
+  rm -rf $OUT/pmc_sq $OUT/pmc_sq2
+  echo sq done
+fi

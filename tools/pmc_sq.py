@@ -1,6 +1,6 @@
 """Per kernel family of one steady-state step: SQ wave-state counters (rocprofv3 --pmc, serialised dispatches).
 WAIT_ANY (parked at s_waitcnt / barrier) + WAIT_INST_ANY (issue stall) + ACTIVE_INST_ANY ~ WAVE_CYCLES (quad-cycles)."""
-import collections, csv, glob, os, sys
+import collections, csv, glob, os, re, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from step_traffic import fam
 
@@ -22,7 +22,8 @@ def load(d):
         n = per[i]["name"]
         k = fam(n)
         if k == "conv_core":
-            k = "conv_q1" if "ELb1E" in n else "conv_q0"
+            m = re.search(r"conv_core_kernelI\w+?Li\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELb([01])E", n)   # Q = 8th template argument
+            k = "conv_q1" if (m and m.group(1) == "1") else "conv_q0"
         for c, v in per[i].items():
             if c != "name":
                 agg[k][c] += v
