@@ -700,8 +700,8 @@ constexpr Shape SHAPES[NSHAPES] = {{128, 64, 256, 0, 256, 9}, {512, 32, 512, 0, 
 // C <= 32 block at its 128-register budget spills 6 - 12 registers once the compiler may interleave the tiles)
 template <typename T, typename TY, int KS, bool Q, bool PE, int EO = -1>
 int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
-    constexpr int EOC = (Q && KS == 3) ? EO : -1;   // conv_core: data gradients only (its forward convs have the plain epilogue)
-    constexpr int EOW = KS == 3 ? EO : -1;          // wave-specialised kernel: forward (EO 8) and data gradients
+    constexpr int EOC = (KS == 3 && (Q || EO == 48)) ? EO : -1;   // conv_core: data gradients and the bias + ReLU forward form (its other forward convs have the plain epilogue)
+    constexpr int EOW = (KS == 3 && EO != 48) ? EO : -1;   // wave-specialised kernel: forward with statistics (EO 8) and data gradients
     switch (shape) {
         case 0:
             if (nva <= 3) return launch<T, TY, KS, 4, 1, 2, 4, 3, Q, PE>(k, grid, lds, st);
@@ -785,6 +785,7 @@ int conv_backend(int path, const stl_conv& p, const ConvK& k, int shape, int nva
         }
         if constexpr (FWD) {
             if (plain && eo == 8) return dispatch<T, T, 3, false, true, 8>(shape, nva, k, grid, lds, st);
+            if (!plain && eo == 48) return dispatch<T, T, 3, false, false, 48>(shape, nva, k, grid, lds, st);
             return plain ? dispatch<T, T, 3, false, true>(shape, nva, k, grid, lds, st) : dispatch<T, T, 3, false, false>(shape, nva, k, grid, lds, st);
         }
     }

@@ -355,6 +355,26 @@ def test_conv_compile_time_epilogue_sets_equal_runtime_form(case, ops, dt, monke
     dxb, rb = dgrad()
     assert not torch.isnan(dxa.float()).any() and torch.equal(dxa, dxb)
     assert torch.allclose(ra, rb, rtol=1e-5, atol=1e-3)
+    monkeypatch.delenv("STL_CONV_NO_EO")
+    if ops == "none" and ks == 3:   # the bias + ReLU forward form of the VGG feature extractors (EO 48)
+        bias = torch.randn(Co, device="cuda", generator=g)
+
+        def vggconv():
+            yk = torch.full((B * H * W * Co,), float("nan"), device="cuda", dtype=ftd)
+            p = capi.Conv()
+            p.dtype, p.B, p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.Co, p.ks, p.stride = fcode, B, H, W, Ci, H, W, Co, 3, 1
+            p.TH, p.TW, p.shape = 0, 0, -1
+            p.src.x, p.src.mode = x0t.data_ptr(), capi.SRC_PLAIN
+            p.w, p.out, p.bias, p.out_relu = wt.data_ptr(), yk.data_ptr(), bias.data_ptr(), 1
+            capi.call("stl_conv_forward", C.byref(p), stream())
+            torch.cuda.synchronize()
+            return yk
+        va = vggconv()
+        monkeypatch.setenv("STL_CONV_NO_EO", "3")
+        vb = vggconv()
+        assert not torch.isnan(va.float()).any() and torch.equal(va, vb)
+        ref = F.relu(F.conv2d(x0t.float().view(B, H, W, Ci).permute(0, 3, 1, 2), wt.float().permute(0, 3, 1, 2), bias, padding=1))
+        assert relerr(from_nhwc(va, B, H, W, Co), ref) < (3e-2 if ftd == torch.bfloat16 else (4e-3 if ftd == torch.float16 else 2e-4))
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
