@@ -104,6 +104,7 @@ int stl_conv_bnadd_ok(const stl_conv* p);
 int stl_debug_conv_stamps(long long* host12);
 int stl_debug_conv_stamps2(long long* host64);
 int stl_debug_wgrad_stamps(long long* host16);
+int stl_debug_wgrad_stamps2(long long* host64);   /* per-tile stamps of block 0 (weight gradient, stamped build) */
 
 /* Weight gradient of the same convolution (aten::convolution_backward, weight part).
  * partial[s][co][tap][ci] (fp32) for s < nsplit; summed later by stl_reduce_slabs.

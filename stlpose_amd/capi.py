@@ -130,6 +130,7 @@ SIGNATURES = {
     "stl_debug_conv_stamps": [vp],
     "stl_debug_conv_stamps2": [vp],
     "stl_debug_wgrad_stamps": [vp],
+    "stl_debug_wgrad_stamps2": [vp],
     "stl_conv_wgrad": [C.POINTER(Wgrad), vp],
     "stl_wgrad_chunk": [C.POINTER(Wgrad)],
     "stl_conv_wgrad_group": [C.POINTER(WgradGroup), vp],

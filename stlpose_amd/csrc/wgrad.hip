@@ -41,13 +41,19 @@ namespace {
 
 // debug-only phase stamps (block 0, thread 0; STL_CONV_STAMPS=1): never read by the kernel
 __device__ long long g_wstamps[16];
+__device__ long long g_wstamps2[64];   // per tile of block 0: [4 i .. 4 i + 3] = tile start, staged image written + barrier, loads of tile i + 2 requested, MFMAs + barrier
 #ifdef STL_STAMPS
 #define WSTAMP(i)                                                                                   \
     do {                                                                                            \
         if (k.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_wstamps[i] = wall_clock64(); \
     } while (0)
+#define WSTAMP2(i)                                                                                  \
+    do {                                                                                            \
+        if (k.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && (i) < 64) g_wstamps2[i] = wall_clock64(); \
+    } while (0)
 #else
 #define WSTAMP(i) do {} while (0)
+#define WSTAMP2(i) do {} while (0)
 #endif
 
 // a * b + c with 24-bit a, b (b uniform): full rate, and kept out of reach of the 64-bit mad combine
@@ -381,13 +387,21 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
     __syncthreads();  // constants visible
     WSTAMP(3);
     bool first = true;
+    [[maybe_unused]] int dbg_i = 0;
     auto body = [&](auto SET) __attribute__((always_inline)) {
+        WSTAMP2(4 * dbg_i);
         write_lds(SET);
         __syncthreads();
+        WSTAMP2(4 * dbg_i + 1);
         if (first) WSTAMP(4);
         if (t + 2 * step < k.npt) fetch(SET, t + 2 * step);   // block-uniform: two tiles ahead, into the set just drained
+        WSTAMP2(4 * dbg_i + 2);
         mfma_tile();
         __syncthreads();
+        WSTAMP2(4 * dbg_i + 3);
+#ifdef STL_STAMPS
+        ++dbg_i;
+#endif
         if (first) WSTAMP(5);
         first = false;
         t += step;
@@ -764,6 +778,9 @@ int stl_wgrad_backend_f32(bool wide, const WgK& k, dim3 grid, size_t lds, hipStr
 #endif
 
 #if STL_DT != 0   // the C ABI entry points live in the bf16 (or the only) unit
+extern "C" int stl_debug_wgrad_stamps2(long long* host64) {
+    return hipMemcpyFromSymbol(host64, HIP_SYMBOL(g_wstamps2), 64 * sizeof(long long)) == hipSuccess ? 0 : stl_set_error("stamps: copy failed");
+}
 extern "C" int stl_debug_wgrad_stamps(long long* host16) {
     return hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_wstamps), 16 * sizeof(long long)) == hipSuccess ? 0 : stl_set_error("stamps: copy failed");
 }
