@@ -36,11 +36,22 @@ def source_id() -> str:
     return h.hexdigest()[:16]
 
 
-def _stale(target: str, deps) -> bool:
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(deps, flags) -> str:
+    """Content hash of an object's inputs (sources it includes + its flags).  Rebuild decisions are by CONTENT, like the build
+    id: a checkout or an `rsync -t` that changes a source while keeping an older mtime must still rebuild."""
+    h = hashlib.sha256(" ".join(flags).encode())
+    for f in deps:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _load_state(path: str) -> dict:
+    try:
+        import json
+        return json.load(open(path))
+    except Exception:
+        return {}
 
 
 def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> str:
@@ -51,7 +62,9 @@ def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> st
     suffix, extra = (".stamps.o", ["-DSTL_STAMPS"]) if stamps else (".o", [])
     srcs = source_files()
     sid = source_id()
-    objs, jobs = [], []
+    state_path = os.path.join(CSRC, ".build_state.json")   # object / library name -> digest of what it was built from
+    state = _load_state(state_path)
+    objs, jobs, digests = [], [], {}
     for s, tag, fl in UNITS:
         src, obj = os.path.join(CSRC, s), os.path.join(CSRC, tag + suffix)
         objs.append(obj)
@@ -59,8 +72,10 @@ def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> st
         deps = srcs if tag == "capi" else [src] + [f for f in srcs if not f.endswith(".hip")]
         if tag == "capi":
             fl = fl + [f'-DSTL_BUILD_ID="{sid}"']
-        if force or _stale(obj, deps):
-            jobs.append([HIPCC, *FLAGS, *extra, *fl, "-c", src, "-o", obj])
+        cmd = [HIPCC, *FLAGS, *extra, *fl, "-c", src, "-o", obj]
+        digests[os.path.basename(obj)] = _digest(deps, cmd[:-1])
+        if force or not os.path.exists(obj) or state.get(os.path.basename(obj)) != digests[os.path.basename(obj)]:
+            jobs.append(cmd)
 
     def run(cmd):
         if verbose:
@@ -72,8 +87,14 @@ def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> st
             print(r.stderr, file=sys.stderr)
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(lib, objs):
+    lib_digest = hashlib.sha256(" ".join(digests[os.path.basename(o)] for o in objs).encode()).hexdigest()[:16]
+    if force or jobs or not os.path.exists(lib) or state.get(os.path.basename(lib)) != lib_digest:
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+    state.update(digests)
+    state[os.path.basename(lib)] = lib_digest
+    import json
+    with open(state_path, "w") as f:
+        json.dump(state, f, indent=0, sort_keys=True)
     if verbose:
         print("build id", sid)
     return lib

@@ -1,6 +1,7 @@
 // Native replay of a planned kernel program: one C call enqueues every launch of the forward or
 // backward plan on its HIP streams, with the cross-stream dependencies expressed as events.
 // (The Python planner builds the op list once; per step the host does O(1) Python work.)
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "common.cuh"
@@ -27,7 +28,16 @@ struct Program {
 // (the host reads results only behind a stream / device synchronisation, which fences on its own).  Round 3, one call, two rounds:
 // 14.69-14.71 ms per step with the default flags, 14.52-14.57 with hipEventDisableSystemFence, 14.66-14.71 with
 // hipEventReleaseToDevice; stream memory operations (hipStreamWriteValue32 / WaitValue32) instead of events: 15.45 (removed).
-static unsigned event_flags() { return hipEventDisableTiming | hipEventDisableSystemFence; }
+// Round 5: STLPOSE_EVENT_FENCE=system (read when a program is created) restores the default, fencing events -- the A/B arm of
+// tests/test_visibility_gpu.py, which hands 64 MB buffers from stream to stream through a program 2000 times and replays the
+// benchmarked train step 300 times under both settings; no stale read under either (the round-4 wrong result was
+// an undersized statistics arena, engine.bn_weight_keys, not visibility: every kernel dispatch carries its own agent-scope
+// acquire and release, the event's fence only adds the system scope).
+static unsigned event_flags() {
+    const char* e = getenv("STLPOSE_EVENT_FENCE");
+    if (e && strcmp(e, "system") == 0) return hipEventDisableTiming;
+    return hipEventDisableTiming | hipEventDisableSystemFence;
+}
 
 // one op of a program on stream `st` (also what the graph builder calls, with the launch recorder set)
 static int run_op(const stl_op& o, void* st, int i) {
@@ -181,6 +191,18 @@ extern "C" int stl_program_run(void* h, void* const* streams) {
 // crashes inside hipStreamEndCapture on ROCm 7.2.  Every op is executed once with the launch recorder set (common.cuh,
 // STL_LAUNCH): its kernels become nodes, chained in issue order; the first node of an op depends on the last node of the
 // previous op of its stream (streams are in-order) and on the last node of every op it waits for.
+// a failed build leaves nothing behind: a retry starts from an empty graph and leaks neither nodes nor argument copies
+static void graph_discard(Program* p) {
+    if (p->graph) (void)hipGraphDestroy(p->graph);
+    p->graph = nullptr;
+    for (StlLaunchRec& r : p->recs) {
+        r.del(r.args_owner);
+        delete[] r.params;
+    }
+    p->recs.clear();
+    p->nnodes = 0;
+}
+
 extern "C" int stl_program_graph_build(void* h) {
     Program* p = static_cast<Program*>(h);
     STL_CHECK(p, "program_graph_build: null program");
@@ -194,8 +216,12 @@ extern "C" int stl_program_graph_build(void* h) {
         g_stl_recorder = &rec;
         const int rc = run_op(o, nullptr, i);
         g_stl_recorder = nullptr;
+        // the program owns every recorded argument copy from here on (graph_discard / stl_program_destroy release them)
+        const size_t first_rec = p->recs.size();
+        for (int k = 0; k < rec.n; ++k) p->recs.push_back(rec.recs[k]);
+        delete[] rec.recs;
         if (rc != 0) {
-            delete[] rec.recs;
+            graph_discard(p);
             return rc;
         }
         std::vector<hipGraphNode_t> deps;
@@ -203,8 +229,8 @@ extern "C" int stl_program_graph_build(void* h) {
         for (int w = 0; w < o.nwait; ++w)
             if (last_of_op[o.wait[w]]) deps.push_back(last_of_op[o.wait[w]]);
         hipGraphNode_t prev = nullptr;
-        for (int k = 0; k < rec.n; ++k) {
-            const StlLaunchRec& r = rec.recs[k];
+        for (size_t k = first_rec; k < p->recs.size(); ++k) {
+            const StlLaunchRec& r = p->recs[k];
             hipKernelNodeParams kp;
             memset(&kp, 0, sizeof(kp));
             kp.func = const_cast<void*>(r.func);
@@ -215,20 +241,29 @@ extern "C" int stl_program_graph_build(void* h) {
             hipGraphNode_t node = nullptr;
             hipError_t e = prev ? hipGraphAddKernelNode(&node, p->graph, &prev, 1, &kp)
                                 : hipGraphAddKernelNode(&node, p->graph, deps.empty() ? nullptr : deps.data(), deps.size(), &kp);
-            p->recs.push_back(r);
             if (e != hipSuccess) {
-                delete[] rec.recs;
+                graph_discard(p);
                 return stl_set_error("program_graph_build: hipGraphAddKernelNode failed for op %d (%s)", i, hipGetErrorString(e));
             }
             prev = node;
             ++p->nnodes;
         }
-        delete[] rec.recs;
-        if (prev) last_of_op[i] = prev, last_of_stream[o.stream] = prev;
-        else last_of_op[i] = last_of_stream[o.stream];   // an op without a launch: whoever waits on it waits on its predecessor
+        if (!prev) {
+            // an op without a launch still carries its cross-stream waits: the planner prunes later waits of this stream on the
+            // strength of them (engine._schedule, transitive ordering), so they become an empty node that its successors chain to
+            if (hipGraphAddEmptyNode(&prev, p->graph, deps.empty() ? nullptr : deps.data(), deps.size()) != hipSuccess) {
+                graph_discard(p);
+                return stl_set_error("program_graph_build: hipGraphAddEmptyNode failed for op %d", i);
+            }
+            ++p->nnodes;
+        }
+        last_of_op[i] = prev, last_of_stream[o.stream] = prev;
     }
     hipError_t e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
-    STL_CHECK(e == hipSuccess, "program_graph_build: hipGraphInstantiate failed (%s)", hipGetErrorString(e));
+    if (e != hipSuccess) {
+        graph_discard(p);
+        return stl_set_error("program_graph_build: hipGraphInstantiate failed (%s)", hipGetErrorString(e));
+    }
     return 0;
 }
 

@@ -164,7 +164,7 @@ class Engine:
         self.out: Optional[torch.Tensor] = None
         self.dout: Optional[torch.Tensor] = None
         # pass 1: count BN channels to size the statistics arenas
-        nstat = sum(int(math.prod(s)) for k, s in store.reg.params if _is_bn_weight(k, store.reg)) * 2 * capi.NSHARD
+        nstat = bn_stat_elems(store.reg)
         self.stats = torch.zeros(max(nstat, 1), dtype=torch.float64, device=self.dev)
         self.rstats = torch.zeros(max(nstat, 1), dtype=torch.float64, device=self.dev) if training else None
         # ---- the planner's knobs (all of them; INTEGRATION.md lists what each is for and what was measured)
@@ -193,10 +193,16 @@ class Engine:
         self._wk_elems = 0
         self._wk_fix: List[Tuple] = []
         walk(self, arch)
+        self._check_stats_arena(nstat)
         self._finalize_weights()
         self._build_tables()
         if training:
             self._build_backward()
+
+    def _check_stats_arena(self, nstat: int):
+        """every layer's [NSHARD][2C] slice must lie inside the arenas: kernels add to them through raw pointers"""
+        if self._stats_used != nstat:
+            raise RuntimeError(f"engine: the plan uses {self._stats_used} statistics elements, the arenas hold {nstat}")
 
     # ------------------------------------------------------------------ allocation helpers
     def _alloc(self, nbytes: int) -> torch.Tensor:
@@ -776,7 +782,7 @@ class Engine:
         exchange module (and, in backward, the weight gradients) run concurrently; fork/join and
         cross-stream dependencies are HIP events inside stl_program_run."""
         h = self._program(ops)
-        if self.graph_mode and ops is not getattr(self, "bwd_ops_events", None):
+        if self.graph_mode:
             if id(ops) not in self._graphs:
                 capi.call("stl_program_graph_build", h)
                 self._graphs.add(id(ops))
@@ -915,19 +921,20 @@ class Engine:
 _STREAM_POOL: Dict[int, Dict] = {}   # device index -> {stream index: (owner object, hipStream_t)}
 
 
-def _is_bn_weight(key: str, reg: Registry) -> bool:
-    return key in _bn_weight_keys(reg)
+def bn_weight_keys(reg: Registry) -> set:
+    """Keys of the BatchNorm scale parameters of `reg` (every ``<bn>.weight`` whose ``<bn>.running_mean`` is a buffer).
+    Computed from the registry itself on every call.  Rounds 2-4 cached this set in a module-level dict keyed by ``id(reg)``:
+    a Registry is created per model, CPython hands a collected registry's address to the next one, and a W32 model built
+    after a ``tiny`` model had been dropped got the TINY key set -- its statistics arenas came out 512 KB short, the
+    producers' atomics of the layers beyond the end landed in whatever followed (and were never zeroed): the one-in-five
+    "output 0.39 off, NaN gradients" failure of the 12th GPU test of round 4 (tests/test_host_cpu.py)."""
+    return {k[: -len("running_mean")] + "weight" for k, _ in reg.buffers if k.endswith("running_mean")}
 
 
-_bn_cache: Dict[int, set] = {}
-
-
-def _bn_weight_keys(reg: Registry) -> set:
-    s = _bn_cache.get(id(reg))
-    if s is None:
-        s = {k[: -len("running_mean")] + "weight" for k, _ in reg.buffers if k.endswith("running_mean")}
-        _bn_cache[id(reg)] = s
-    return s
+def bn_stat_elems(reg: Registry) -> int:
+    """fp64 elements of one statistics arena: [NSHARD][2C] per BatchNorm layer."""
+    keys = bn_weight_keys(reg)
+    return sum(int(math.prod(s)) for k, s in reg.params if k in keys) * 2 * capi.NSHARD
 
 
 def _to_device(ctab, device) -> torch.Tensor:

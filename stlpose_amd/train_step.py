@@ -49,10 +49,20 @@ class TrainStep:
         if self.dp is not None:
             self.eng.graph_mode = False   # the per-bucket all-reduce picks buckets up at the program's EVENTS (stl_program_wait_op)
         self._comm: Optional[torch.cuda.Stream] = None
-        self._dp_backend = ""
+        # per-bucket issue needs a collective that is a KERNEL on the communicator's stream (RCCL).  Decide by the backend serving
+        # CUDA tensors: a default-initialised group reports e.g. "cpu:gloo,cuda:nccl" or "undefined" from get_backend()
+        self._dp_rccl = False
         if process_group is not None:
             import torch.distributed as dist
-            self._dp_backend = str(dist.get_backend(process_group))
+            try:
+                name = process_group._get_backend(torch.device("cuda")).name()
+            except Exception:
+                name = str(dist.get_backend(process_group))
+            self._dp_rccl = "nccl" in str(name).lower()
+            if not self._dp_rccl and os.environ.get("RANK", "0") == "0":
+                import warnings
+                warnings.warn(f"stlpose_amd.TrainStep: process group backend {name!r} is not RCCL -- gradient buckets are all-reduced "
+                              "behind the whole backward pass (no overlap)")
         self._force_dp = os.environ.get("STLPOSE_DP_FORCE", "0") == "1"   # exercise the DP path with one rank (tests)
         self.world = self.dp.world if self.dp is not None else 1
         n = self.store.nparam
@@ -131,7 +141,7 @@ class TrainStep:
             capi.call("stl_optim_begin_step", self.step_count.data_ptr(), st)
         # per-bucket issue while backward is being enqueued: RCCL only ("nccl": the collective is a kernel enqueued on the
         # communicator's stream, the host does not wait); gloo's all-reduce of a device tensor makes the host wait for the stream
-        dp_on = self.dp is not None and (self.world > 1 or self._force_dp) and not self.use_graph and self._dp_backend == "nccl"
+        dp_on = self.dp is not None and (self.world > 1 or self._force_dp) and not self.use_graph and self._dp_rccl
         e.backward(st, fused_optim=fused_optim, on_bucket=self._issue_bucket if dp_on else None)
         self._buckets_issued = dp_on
         if fused_optim:

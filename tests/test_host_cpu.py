@@ -209,3 +209,40 @@ def test_in_program_optimizer_ops_are_ordered_behind_the_last_readers(monkeypatc
                 direct = any(ops[w][2] == ops[j][2] and w >= j for w in waits[k])
                 earlier = any(ops[w][2] == ops[j][2] and w >= j for kk in range(k) if ops[kk][2] == o[2] for w in waits[kk])
                 assert same or direct or earlier, (k, t)
+
+
+def test_statistics_arena_is_sized_from_the_registry_itself_not_from_an_id_keyed_cache(monkeypatch):
+    """Round-4's one-in-five wrong result (output 0.39 off, NaN gradients in the 12th GPU test of a process): the BatchNorm key
+    set was cached per ``id(registry)``; CPython re-uses the address of a collected registry, so a W32 model built after a dropped
+    ``tiny`` model sized its statistics arenas with the tiny key set (11168 of 27168 channels: 512 KB short) and the kernels'
+    atomics ran past the end.  The size now comes from the registry on every call, and the planner refuses a plan whose
+    statistics slices do not fill the arena exactly."""
+    import gc
+    import random
+    from stlpose_amd import PoseHighResolutionNet, capi, engine
+    from stlpose_amd.arch import ARCHS, registry
+    want = {a: 2 * capi.NSHARD * sum(s[0] for k, s in registry(ARCHS[a]).buffers if k.endswith("running_mean")) for a in ARCHS}
+    assert want["w32"] == 27168 * 2 * capi.NSHARD and want["tiny"] < want["w32"] < want["w48"]
+    random.seed(0)
+    seen, reused = {}, 0
+    for _ in range(600):   # address re-use across architectures happens within a few dozen iterations
+        a = random.choice(list(ARCHS))
+        r = registry(ARCHS[a])
+        reused += seen.get(id(r), a) != a
+        seen[id(r)] = a
+        assert engine.bn_stat_elems(r) == want[a]
+        del r
+        gc.collect(0)
+    assert reused > 0, "the loop never re-used a registry address for another architecture: the test lost its point"
+    # the planner's own check: tiny plan, then W32 plans in the same process
+    for arch in ("tiny", "w32", "tiny", "w32"):
+        m = PoseHighResolutionNet(arch, "fp32")
+        m._pack(torch.device("cpu"))
+        e = engine.Engine(m.arch, m._store, 2, 64, 64, capi.F32, True)
+        assert e.stats.numel() == e.rstats.numel() == e._stats_used == want[arch]
+        del m, e
+    m = PoseHighResolutionNet("w32", "fp32")
+    m._pack(torch.device("cpu"))
+    monkeypatch.setattr(engine, "bn_stat_elems", lambda reg: want["tiny"])   # what the stale cache entry amounted to
+    with pytest.raises(RuntimeError, match="statistics elements"):
+        engine.Engine(m.arch, m._store, 2, 64, 64, capi.F32, True)

@@ -1,0 +1,132 @@
+"""GPU: cross-stream visibility of the native program (csrc/program.hip) under both event flag settings.
+
+Every cross-stream dependency of a planned program is a HIP event created with ``hipEventDisableSystemFence``
+(round 3: 0.15 ms per step).  The round-4 review named that flag as the prime suspect for a one-in-five wrong result;
+the cause turned out to be an undersized statistics arena (``tests/test_host_cpu.py::test_statistics_arena_…``), and these
+two stresses are what clears the flag: (a) a two-stream hand-off of a 64 MB buffer through ``stl_program_create`` itself,
+pattern k = 1 … N with every buffer re-used each iteration, (b) the benchmarked train step replayed on a fixed batch with
+the optimiser off, every step's flat gradient compared with the first one's.  Both run with the events as shipped and with
+``STLPOSE_EVENT_FENCE=system`` (default, fencing events): the two settings must behave the same -- no stale element."""
+import ctypes as C
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from stlpose_amd import PoseHighResolutionNet, capi  # noqa: E402
+from stlpose_amd.train_step import TrainStep  # noqa: E402
+
+N_PINGPONG = int(os.environ.get("STL_VIS_PINGPONG", "2000"))
+N_STEPS = int(os.environ.get("STL_VIS_STEPS", "300"))
+
+
+def _copy_op(src: torch.Tensor, dst: torch.Tensor, B, H, W, Cc) -> capi.Fuse:
+    """out = src through the product's sum kernel (one plain term, no ReLU): a pure copy."""
+    p = capi.Fuse()
+    p.dtype, p.B, p.H, p.W, p.C, p.nterms, p.relu = capi.BF16, B, H, W, Cc, 1, 0
+    p.t[0].src.x, p.t[0].src.mode, p.t[0].shift = src.data_ptr(), capi.SRC_PLAIN, 0
+    p.out = dst.data_ptr()
+    return p
+
+
+@pytest.mark.parametrize("fence", ["device", "system"])
+def test_two_stream_handoff_through_a_program_never_reads_stale_data(fence, monkeypatch):
+    """main stream fills A with pattern k -> [program: stream 1 copies A -> B, records; stream 2 waits, copies B -> C; stream 3
+    waits on 2, copies C -> D] -> main stream (behind the program's join) counts elements of D that are not k.  B, C, D are
+    64 MB each and rewritten every iteration, so a consumer that misses an invalidate (or a producer whose write-back has not
+    happened) reads iteration k-1's value.  Uneven load: a fourth op keeps stream 0 streaming another 64 MB buffer."""
+    if fence == "system":
+        monkeypatch.setenv("STLPOSE_EVENT_FENCE", "system")
+    else:
+        monkeypatch.delenv("STLPOSE_EVENT_FENCE", raising=False)
+    lib = capi.lib()
+    dev = torch.device("cuda", 0)
+    B, H, W, Cc = 32, 128, 128, 64          # 32 Mi elements of bf16 = 64 MiB
+    n = B * H * W * Cc
+    bufs = [torch.zeros(n, dtype=torch.bfloat16, device=dev) for _ in range(6)]
+    A, Bb, Cb, D, E, F = bufs
+    descs = [_copy_op(A, Bb, B, H, W, Cc), _copy_op(E, F, B, H, W, Cc), _copy_op(Bb, Cb, B, H, W, Cc), _copy_op(Cb, D, B, H, W, Cc)]
+    ops = (capi.Op * 4)()
+    # op 0: stream 1 (records) | op 1: stream 0 (load beside it) | op 2: stream 2 waits op 0 (records) | op 3: stream 3 waits op 2
+    for i, (strm, waits, rec) in enumerate([(1, [], 1), (0, [], 0), (2, [0], 1), (3, [2], 0)]):
+        o = ops[i]
+        o.kind, o.stream, o.desc = capi.OP_KIND["stl_fuse_forward"], strm, C.addressof(descs[i])
+        o.nwait, o.record = len(waits), rec
+        for j, w in enumerate(waits):
+            o.wait[j] = w
+    h = C.c_void_p()
+    capi.call("stl_program_create", ops, 4, 4, C.byref(h))
+    side = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    arr = (C.c_void_p * 4)()
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    try:
+        main = torch.cuda.current_stream(dev)
+        arr[0] = main.cuda_stream
+        for i, s in enumerate(side):
+            arr[i + 1] = s.cuda_stream
+        for k in range(1, N_PINGPONG + 1):
+            v = float(k % 251 + 1)          # exactly representable in bf16 (integers <= 256)
+            A.fill_(v)
+            assert lib.stl_program_run(h, arr) == 0, lib.stl_last_error().decode()
+            bad += (D != v).sum()
+        torch.cuda.synchronize()
+    finally:
+        capi.call("stl_program_destroy", h)
+    assert int(bad.item()) == 0, f"{int(bad.item())} stale elements over {N_PINGPONG} hand-offs ({fence}-scope events)"
+
+
+def _fixed_batch(Bn, H, W, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(Bn, 3, H, W, generator=g)
+    hh, ww = H // 4, W // 4
+    cx = torch.randint(0, ww, (Bn, 17, 1, 1), generator=g).float()
+    cy = torch.randint(0, hh, (Bn, 17, 1, 1), generator=g).float()
+    ys, xs = torch.arange(hh).view(1, 1, hh, 1).float(), torch.arange(ww).view(1, 1, 1, ww).float()
+    tgt = torch.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) / 18.0)
+    tw = (torch.rand(Bn, 17, 1, generator=g) < 0.8).float()
+    return img, tgt, tw
+
+
+# (dtype, replays, bar on the worst gradient deviation relative to the largest gradient element).  fp32: only the order of the
+# fp64 statistics atomics varies between replays.  mixed: a BatchNorm constant that moves by one fp32 ulp can flip the f16 / bf16
+# rounding of single activations, so the bar is the measured noise floor times a margin, still orders of magnitude below what a
+# stale or half-written tensor does (O(1)).
+REPLAY_CASES = [("fp32", max(1, N_STEPS // 3), 1e-5), ("mixed", N_STEPS, 1e-3)]
+
+
+@pytest.mark.parametrize("fence", ["device", "system"])
+@pytest.mark.parametrize("dtype,nrep,bar", REPLAY_CASES)
+def test_replayed_train_step_gives_the_same_gradient_every_time(fence, dtype, nrep, bar, monkeypatch):
+    """The benchmarked plan (W32, 384x288, batch 32, four streams, ~370 event dependencies per step), fixed batch, optimiser
+    off: the flat gradient of every replay must equal the first one's up to the order noise of the atomics.  Plan buffers are
+    re-used every step; a consumer that runs before its producer's data is visible reads a half-written tensor."""
+    if fence == "system":
+        monkeypatch.setenv("STLPOSE_EVENT_FENCE", "system")
+    else:
+        monkeypatch.delenv("STLPOSE_EVENT_FENCE", raising=False)
+    torch.manual_seed(21)
+    m = PoseHighResolutionNet("w32", dtype).cuda()
+    ts = TrainStep(m, 32, 384, 288, optimizer="sgd", lr=0.0, momentum=0.0)
+    img, tgt, tw = _fixed_batch(32, 384, 288, seed=9)
+    ts.load_batch(img.cuda(), tgt.cuda(), tw.cuda())
+    ts._fwd_bwd(update_running=False)
+    torch.cuda.synchronize()
+    g0 = ts.store.grads.clone()
+    l0 = ts.loss.clone()
+    scale = float(g0.abs().max())
+    assert scale > 0 and torch.isfinite(g0).all()
+    worst = torch.zeros((), dtype=torch.float32, device=g0.device)
+    lworst = torch.zeros((), dtype=torch.float32, device=g0.device)
+    for _ in range(nrep):
+        ts._fwd_bwd(update_running=False)
+        worst = torch.maximum(worst, (ts.store.grads - g0).abs().max())
+        lworst = torch.maximum(lworst, (ts.loss - l0).abs())
+    torch.cuda.synchronize()
+    rel = float(worst) / scale
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", f"visibility_replay_{dtype}_{fence}.txt"), "w") as f:
+        f.write(f"{nrep} replays, {dtype}, {fence}-scope events: worst gradient deviation {rel:.3e} of the largest element, loss deviation {float(lworst):.3e}\n")
+    assert rel < bar, f"gradient moved by {rel:.3e} of its largest element between replays ({fence}-scope events)"
+    assert float(lworst) < bar * abs(float(l0)) + 1e-7
