@@ -7,8 +7,8 @@
  * computation it replaces.  Conventions:
  *   - plain pointers + sizes only; all tensor pointers are DEVICE pointers owned by the caller
  *     (the Python host allocates them with torch); kernels never allocate;
- *   - activations are NHWC ("channels last"), element type `dtype` = STL_F32 | STL_BF16,
- *     accumulation always fp32, BatchNorm statistics fp64;
+ *   - activations are NHWC ("channels last"), element type `dtype` = STL_F32 | STL_BF16 | STL_F16 (mixed 16-bit mode:
+ *     forward tensors STL_F16, gradients STL_BF16, see STL_DT2 / ydtype), accumulation always fp32, BatchNorm statistics fp64;
  *   - every call enqueues on `stream` (a hipStream_t passed as void*) and returns without
  *     synchronising, so a whole step can be captured in a hipGraph;
  *   - return value 0 = ok, negative = error (message via stl_last_error()); the Python mirror
@@ -100,11 +100,6 @@ int stl_conv_forward(const stl_conv* p, void* stream);
 int stl_conv_plan(stl_conv* p);
 /* 1 when stl_conv_forward has a kernel variant that takes p (already planned) with a STL_SRC_BNADD source. */
 int stl_conv_bnadd_ok(const stl_conv* p);
-/* Debug: phase time stamps (100 MHz ticks) of block 0 of the last conv launched with STL_CONV_STAMPS=1. */
-int stl_debug_conv_stamps(long long* host12);
-int stl_debug_conv_stamps2(long long* host64);
-int stl_debug_wgrad_stamps(long long* host16);
-int stl_debug_wgrad_stamps2(long long* host64);   /* per-tile stamps of block 0 (weight gradient, stamped build) */
 
 /* Weight gradient of the same convolution (aten::convolution_backward, weight part).
  * partial[s][co][tap][ci] (fp32) for s < nsplit; summed later by stl_reduce_slabs.
@@ -243,15 +238,22 @@ typedef struct stl_bnrec { /* one BatchNorm layer */
     int32_t C;
     float inv_count;
 } stl_bnrec;
-/* running_mean/var momentum update (unbiased var), reference nn.BatchNorm2d(momentum=0.1). */
+/* running_mean/var momentum update (unbiased var), reference nn.BatchNorm2d(momentum=0.1).
+ * overflow (device int32, NULL = off; the caller initialises it to INT32_MAX): range guard of the 16-bit forward tensors.  A raw
+ * conv output beyond the storage type's range (STL_F16: |y| > 65504, e.g. a badly scaled checkpoint, lib/model_setup.py:38-42
+ * loads arbitrary ones) is stored as infinity and shows in the layer's sums; such a layer keeps its running statistics and the
+ * smallest index i of tab[] with non-finite sums is left in *overflow (atomic min).  The optimisers below skip elements whose
+ * gradient is not finite, so the step that overflowed leaves the weights as they were; the host reads the word when it reads
+ * the loss (TrainStep.check_forward_range) and raises with the layer's name. */
 int stl_bn_running_update(const double* stats, float* buffers, int64_t* num_batches_tracked /* [n] or NULL */,
-                          const stl_bnrec* tab, int n, float momentum, void* stream);
+                          const stl_bnrec* tab, int n, float momentum, int32_t* overflow, void* stream);
 /* dgamma = r2, dbeta = r1 from the backward reduction arena into the flat grad buffer. */
 int stl_bn_param_grads(const double* rstats, float* grads, const stl_bnrec* tab, int n, void* stream);
 
 /* Optimisers over the flat fp32 master (torch.optim.Adam / SGD semantics, reference
  * lib/model_setup.py:135-141).  hyper = device float[8]: lr, beta1, beta2, eps, weight_decay,
- * momentum, nesterov, gscale;  step = device int32 (incremented by the kernel). */
+ * momentum, nesterov, gscale;  step = device int32 (incremented by the kernel).  An element whose gradient is
+ * NaN or infinite is left untouched (weight and moments): see stl_bn_running_update. */
 int stl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
                   int32_t* step, void* stream);
 int stl_sgd_step(float* p, const float* g, float* mom, int64_t n, const float* hyper, int32_t* step,

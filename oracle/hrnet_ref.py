@@ -237,15 +237,15 @@ class bf16_storage:
             if not isinstance(m, nn.Conv2d):
                 continue
             head = name == "final_layer"
-            self.handles.append(m.register_forward_pre_hook(lambda mod, args: (self._r(args[0]),)))
+            self.handles.append(m.register_forward_pre_hook(lambda mod, args: (type(self)._r(args[0]),)))
             if not head:
                 self.saved[name] = m.weight.data
-                m.weight.data = self._r(m.weight.data)
-                self.handles.append(m.register_forward_hook(lambda mod, args, out: self._r(out)))
+                m.weight.data = type(self)._r(m.weight.data)
+                self.handles.append(m.register_forward_hook(lambda mod, args, out: type(self)._r(out)))
         import re
 
         def round_out(mod, args, out):
-            return [self._r(t) for t in out] if isinstance(out, (list, tuple)) else self._r(out)
+            return [type(self)._r(t) for t in out] if isinstance(out, (list, tuple)) else type(self)._r(out)
         for name, m in self.model.named_modules():
             if isinstance(m, (TwoConvUnit, ThreeConvUnit, ExchangeModule)) or re.fullmatch(r"transition\d\.\d", name):
                 self.handles.append(m.register_forward_hook(round_out))
@@ -259,3 +259,13 @@ class bf16_storage:
             mods[name].weight.data = w
         self.handles, self.saved = [], {}
         return False
+
+
+class f16_storage(bf16_storage):
+    """The same rounding points with IEEE half (10 mantissa bits): the FORWARD side of the HIP mixed 16-bit mode (forward
+    tensors and forward kernel-layout weights f16).  The mixed-mode parity bars are tied to this run: it must
+    pass them itself (tests/test_parity_r3_gpu.py)."""
+
+    @staticmethod
+    def _r(t: torch.Tensor) -> torch.Tensor:
+        return t.to(torch.float16).to(t.dtype)

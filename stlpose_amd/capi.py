@@ -127,10 +127,6 @@ SIGNATURES = {
     "stl_conv_forward": [C.POINTER(Conv), vp],
     "stl_conv_plan": [C.POINTER(Conv)],
     "stl_conv_bnadd_ok": [C.POINTER(Conv)],
-    "stl_debug_conv_stamps": [vp],
-    "stl_debug_conv_stamps2": [vp],
-    "stl_debug_wgrad_stamps": [vp],
-    "stl_debug_wgrad_stamps2": [vp],
     "stl_conv_wgrad": [C.POINTER(Wgrad), vp],
     "stl_wgrad_chunk": [C.POINTER(Wgrad)],
     "stl_conv_wgrad_group": [C.POINTER(WgradGroup), vp],
@@ -152,7 +148,7 @@ SIGNATURES = {
     "stl_sgd_slice": [vp, vp, vp, i64, vp, vp, vp],
     "stl_reduce_slabs": [vp, vp, vp, i32, i32, vp],
     "stl_reduce_slabs_range": [C.POINTER(ReduceRange), vp],
-    "stl_bn_running_update": [vp, vp, vp, vp, i32, f32, vp],
+    "stl_bn_running_update": [vp, vp, vp, vp, i32, f32, vp, vp],
     "stl_bn_param_grads": [vp, vp, vp, i32, vp],
     "stl_adam_step": [vp, vp, vp, vp, i64, vp, vp, vp],
     "stl_sgd_step": [vp, vp, vp, i64, vp, vp, vp],
@@ -175,6 +171,10 @@ SIGNATURES = {
     "stl_version": [],
 }
 
+# include/stlpose_hip_debug.h: exported by the stamped diagnostic build only (STLPOSE_HIP_LIB=.../libstlpose_hip_stamps.so)
+DEBUG_SIGNATURES = {"stl_debug_conv_stamps": [vp], "stl_debug_conv_stamps2": [vp], "stl_debug_wgrad_stamps": [vp],
+                    "stl_debug_wgrad_stamps2": [vp]}
+
 STRING_FUNCS = ("stl_last_error", "stl_build_id", "stl_last_kernel")   # const char* f(void)
 
 _lib = None
@@ -193,6 +193,9 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)  # AttributeError if the ABI and this table disagree
             fn.argtypes = args
             fn.restype = C.c_int
+        for name, args in DEBUG_SIGNATURES.items():
+            if hasattr(l, name):
+                getattr(l, name).argtypes, getattr(l, name).restype = args, C.c_int
         for name in STRING_FUNCS:
             fn = getattr(l, name)
             fn.argtypes = []

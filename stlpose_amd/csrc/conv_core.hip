@@ -56,13 +56,14 @@ namespace {
 
 constexpr int PSA = 96;
 
-// debug-only phase stamps (block 0, thread 0; enabled by STL_CONV_STAMPS=1): never read by the kernel
-__device__ long long g_stamps[32];
-__device__ long long g_stamps2[64];  // wave-specialised kernel: [0..23] loader, [32..55] compute (6 stages x 4)
 // Compiled in only with -DSTL_STAMPS (python -m stlpose_amd.build --stamps -> libstlpose_hip_stamps.so): even when
 // disabled at run time, the stores make the compiler place s_waitcnt vmcnt() in front of whatever reuses their data
 // registers -- in the stage loop that drains loads which were meant to stay in flight.
 #ifdef STL_STAMPS
+#include "../../include/stlpose_hip_debug.h"
+// debug-only phase stamps (block 0, thread 0; enabled by STL_CONV_STAMPS=1): never read by the kernel
+__device__ long long g_stamps[32];
+__device__ long long g_stamps2[64];  // wave-specialised kernel: [0..23] loader, [32..55] compute (6 stages x 4)
 #define STAMP(i)                                                          \
     do {                                                                  \
         if (k.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); \
@@ -913,12 +914,14 @@ int stl_conv_backend_f16(int path, const stl_conv& p, const ConvK& k, int shape,
 #endif
 
 #if STL_HAS_BF16   // the C ABI entry points live in the bf16 (or the only) unit
+#ifdef STL_STAMPS
 extern "C" int stl_debug_conv_stamps(long long* host12) {
     return hipMemcpyFromSymbol(host12, HIP_SYMBOL(g_stamps), 14 * sizeof(long long)) == hipSuccess ? 0 : stl_set_error("stamps: copy failed");
 }
 extern "C" int stl_debug_conv_stamps2(long long* host64) {
     return hipMemcpyFromSymbol(host64, HIP_SYMBOL(g_stamps2), 64 * sizeof(long long)) == hipSuccess ? 0 : stl_set_error("stamps: copy failed");
 }
+#endif
 
 extern "C" int stl_conv_plan(stl_conv* pp) {
     stl_conv& p = *pp;

@@ -686,14 +686,22 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* partials
 }
 
 __global__ __launch_bounds__(256) void bn_running_kernel(const double* stats, float* buffers, int64_t* nbt,
-                                                         const stl_bnrec* tab, float momentum) {
+                                                         const stl_bnrec* tab, float momentum, int32_t* overflow) {
     const stl_bnrec e = tab[blockIdx.x];
     const double n = 1.0 / (double)e.inv_count;
+    bool bad = false;
     for (int c = threadIdx.x; c < e.C; c += 256) {
         double s0 = 0.0, s1 = 0.0;
         for (int k = 0; k < STL_NSHARD; ++k) {
             s0 += stats[e.stats_off + (int64_t)k * 2 * e.C + c];
             s1 += stats[e.stats_off + (int64_t)k * 2 * e.C + e.C + c];
+        }
+        // A raw conv output beyond the range of its storage type (f16 forward tensors of the mixed mode: |y| > 65504) was stored
+        // as infinity, and the sums of the values AS STORED carry it: the layer's running statistics stay as they are and the
+        // FIRST such layer (smallest index) is reported through `overflow` (engine.Engine.check_forward_range).
+        if (!(fabs(s0) <= 1.7e308 && fabs(s1) <= 1.7e308)) {
+            bad = true;
+            continue;
         }
         const double mean = s0 / n;
         double var = s1 / n - mean * mean;
@@ -705,6 +713,7 @@ __global__ __launch_bounds__(256) void bn_running_kernel(const double* stats, fl
         rv[c] = (float)((1.0 - momentum) * (double)rv[c] + momentum * unb);
     }
     if (threadIdx.x == 0 && nbt) nbt[blockIdx.x] += 1;
+    if (bad && overflow) atomicMin(overflow, (int32_t)blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void bn_param_grads_kernel(const double* rstats, float* grads, const stl_bnrec* tab) {
@@ -731,6 +740,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
     const float step_size = lr / bc1, isq2 = 1.f / sqrtf(bc2);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float gi = g[i] * gs;
+        if (!(fabsf(gi) <= 3.4e38f)) continue;   // non-finite gradient (forward overflow, see bn_running_kernel): keep the weights
         const float pi = p[i];
         if (wd != 0.f) gi = fmaf(wd, pi, gi);
         const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -746,6 +756,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, floa
     const bool first = step[0] <= 1;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float gi = g[i] * gs;
+        if (!(fabsf(gi) <= 3.4e38f)) continue;   // non-finite gradient: keep the weights (adam_kernel)
         const float pi = p[i];
         if (wd != 0.f) gi = fmaf(wd, pi, gi);
         if (mu != 0.f) {
@@ -1180,9 +1191,9 @@ extern "C" int stl_reduce_slabs_range(const stl_reduce_range* r, void* stream) {
 }
 
 extern "C" int stl_bn_running_update(const double* stats, float* buffers, int64_t* nbt, const stl_bnrec* tab, int n,
-                                     float momentum, void* stream) {
+                                     float momentum, int32_t* overflow, void* stream) {
     if (n == 0) return 0;
-    STL_LAUNCH(bn_running_kernel, dim3(n), dim3(256), 0, ST, stats, buffers, nbt, tab, momentum);
+    STL_LAUNCH(bn_running_kernel, dim3(n), dim3(256), 0, ST, stats, buffers, nbt, tab, momentum, overflow);
     STL_LAUNCH_CHECK("bn_running_update");
     return 0;
 }

@@ -39,10 +39,11 @@ namespace {
 
 #include "conv_common.inc"
 
+#ifdef STL_STAMPS
+#include "../../include/stlpose_hip_debug.h"
 // debug-only phase stamps (block 0, thread 0; STL_CONV_STAMPS=1): never read by the kernel
 __device__ long long g_wstamps[16];
 __device__ long long g_wstamps2[64];   // per tile of block 0: [4 i .. 4 i + 3] = tile start, staged image written + barrier, loads of tile i + 2 requested, MFMAs + barrier
-#ifdef STL_STAMPS
 #define WSTAMP(i)                                                                                   \
     do {                                                                                            \
         if (k.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_wstamps[i] = wall_clock64(); \
@@ -778,12 +779,14 @@ int stl_wgrad_backend_f32(bool wide, const WgK& k, dim3 grid, size_t lds, hipStr
 #endif
 
 #if STL_DT != 0   // the C ABI entry points live in the bf16 (or the only) unit
+#ifdef STL_STAMPS
 extern "C" int stl_debug_wgrad_stamps2(long long* host64) {
     return hipMemcpyFromSymbol(host64, HIP_SYMBOL(g_wstamps2), 64 * sizeof(long long)) == hipSuccess ? 0 : stl_set_error("stamps: copy failed");
 }
 extern "C" int stl_debug_wgrad_stamps(long long* host16) {
     return hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_wstamps), 16 * sizeof(long long)) == hipSuccess ? 0 : stl_set_error("stamps: copy failed");
 }
+#endif
 
 extern "C" int stl_wgrad_chunk(const stl_wgrad* pp) { return wgrad_chunk(*pp); }
 

@@ -167,6 +167,7 @@ class Engine:
         nstat = bn_stat_elems(store.reg)
         self.stats = torch.zeros(max(nstat, 1), dtype=torch.float64, device=self.dev)
         self.rstats = torch.zeros(max(nstat, 1), dtype=torch.float64, device=self.dev) if training else None
+        self.overflow = torch.full((1,), 2 ** 31 - 1, dtype=torch.int32, device=self.dev)   # range guard, see check_forward_range
         # ---- the planner's knobs (all of them; INTEGRATION.md lists what each is for and what was measured)
         env = os.environ.get
         self.nstreams = int(env("STLPOSE_STREAMS", "4"))          # HIP streams = hardware queues of the plan (4 compute pipes)
@@ -846,7 +847,26 @@ class Engine:
         if self.training and update_running:
             st = self.store
             capi.call("stl_bn_running_update", self.stats.data_ptr(), st.bufs.data_ptr(), st.nbt.data_ptr(),
-                      self._bn_tab.data_ptr(), len(self.bns), MOMENTUM, stream)
+                      self._bn_tab.data_ptr(), len(self.bns), MOMENTUM, self.overflow.data_ptr(), stream)
+
+    NO_OVERFLOW = 2 ** 31 - 1
+
+    def check_forward_range(self):
+        """Raise if a forward pass since the last call stored a non-finite raw conv output (one 4-byte read: call it where the
+        host reads the loss anyway).  Training mode only: the guard rides on the BatchNorm statistics (stl_bn_running_update)."""
+        i = int(self.overflow.item())
+        if i == self.NO_OVERFLOW:
+            return
+        self.overflow.fill_(self.NO_OVERFLOW)
+        bn = self.bns[i]
+        name = next((k for k, off in self.store.param_off.items() if off == bn.param_off), f"BatchNorm #{i}")
+        what = {capi.F16: "f16 (|y| > 65504)", capi.BF16: "bf16", capi.F32: "fp32"}[self.fdtype]
+        raise FloatingPointError(
+            f"stlpose_amd: the raw output of the convolution in front of {name[:-len('.weight')] if name.endswith('.weight') else name} "
+            f"left the range of its {what} storage (non-finite BatchNorm statistics; first such layer in forward order).  "
+            "The optimiser skipped that step, the weights and running statistics are intact.  Forward tensors of the default "
+            "'mixed' mode are f16; for a checkpoint with badly scaled weights use compute_dtype='bf16' (same speed, bf16 range) "
+            "or 'fp32'.")
 
     def backward(self, stream: int, fused_optim: bool = False, on_bucket=None):
         """expects self.dout filled; leaves dL/dparam in store.grads (overwrites).  fused_optim: the program of

@@ -272,6 +272,12 @@ class Evaluator:
         output = forward_pass(model=self.model, img=imgs, model_name=self.model_name, device=self.device, flip=self.flip)
         loss = float(self.loss_function(output, target, target_weight.float().to(self.device)).item())
         keypoints, max_vals, _ = get_final_preds_hrnet(heatmaps=output, center=centers, scale=scales)
+        if not np.isfinite(np.asarray(max_vals)).all():
+            # eval mode has no batch statistics to carry the range guard of the training step (Engine.check_forward_range): a
+            # forward tensor beyond its 16-bit range ends as a non-finite heat map -- say so instead of scoring NaNs
+            raise FloatingPointError(
+                "stlpose_amd.Evaluator: non-finite heat maps.  With compute_dtype='mixed' (f16 forward tensors, |y| <= 65504) a "
+                "badly scaled checkpoint overflows; evaluate it with compute_dtype='bf16' or 'fp32'.")
         return loss, float(accuracy(output, target)[1]), keypoints, max_vals
 
     @torch.no_grad()

@@ -120,6 +120,11 @@ class TrainStep:
         self.target.copy_(target, non_blocking=True)
         self.tweight.copy_(target_weight.reshape(self.tweight.shape), non_blocking=True)
 
+    def check_forward_range(self):
+        """Raise FloatingPointError if a step since the last call overflowed the 16-bit forward tensors (4-byte device read:
+        call it where the host synchronises anyway -- Trainer does at every accuracy / epoch-loss read)."""
+        self.eng.check_forward_range()
+
     def invalidate_weights(self):
         """Call after changing the model's parameters outside of step() (load_state_dict, manual edits)."""
         self._prepped = False

@@ -289,6 +289,8 @@ class Trainer:
             if i % self.acc_every == 0:
                 _, avg_acc, _, _ = accuracy(self.ts.eng.out.detach(), target)
                 accs.append(avg_acc)
+                self.ts.check_forward_range()      # the heat maps just came to the host: one more 4-byte read
+        self.ts.check_forward_range()
         self.train_loss = float(torch.stack(losses).mean().item()) if losses else 1e18
         self.train_acc = float(np.mean(accs)) if accs else 0.0
 

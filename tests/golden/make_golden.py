@@ -27,6 +27,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.environ.get("STL_GOLDEN_OUT") or HERE   # where the fixtures are written (tests regenerate into a scratch directory)
 REF = "/root/reference/src"
 sys.dont_write_bytecode = True
 sys.path.insert(0, ROOT)
@@ -86,6 +87,18 @@ def _install_shims(tmpdir):
     sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
     import CONFIG as ref_config
     ref_config.CONFIG["paths"]["pretrained_path"] = tmpdir
+
+
+def _shim_dir() -> str:
+    """The directory the reference reads its architecture YAML from (CONFIG["paths"]["pretrained_path"]): created and wired
+    in by the first caller, RE-USED by every later generator of the process.  (Until round 4 every gen_* made a fresh temp
+    dir but left the reference's CONFIG pointing at main()'s, whose last YAML is W32: run without an argument, the script
+    wrote a W32 net into g8_w48_train.npz.)"""
+    if "CONFIG" in sys.modules:
+        return sys.modules["CONFIG"].CONFIG["paths"]["pretrained_path"]
+    tmp = tempfile.mkdtemp(prefix="stl_golden_")
+    _install_shims(tmp)
+    return tmp
 
 
 def _write_yaml(tmpdir, arch):
@@ -151,8 +164,7 @@ def _grad_norms(model):
 
 def main():
     torch.set_num_threads(8)
-    tmp = tempfile.mkdtemp(prefix="stl_golden_")
-    _install_shims(tmp)
+    tmp = _shim_dir()
     from lib.loss import PersonMSELoss
     from lib.inference import forward_pass
     from lib.pose_parsing import get_max_preds_hrnet, get_final_preds_hrnet
@@ -189,7 +201,7 @@ def main():
         for k, v in m.named_buffers():
             if k.startswith(("bn1.", "bn2.", "stage4.1.fuse_layers.3.0.2.1", "stage3.0.branches.2.1.bn2")):
                 fx["buf/" + k] = v.numpy()
-        np.savez_compressed(os.path.join(HERE, f"g1_tiny_{mode}.npz"), **fx)
+        np.savez_compressed(os.path.join(OUT, f"g1_tiny_{mode}.npz"), **fx)
         print("G1", mode, "loss", loss.item(), "out", out.shape)
 
     # ---- G3/G4/G5: full W32 at 256x192 (cfg1) and 384x288, train-mode fwd+loss+bwd, eval flip-test
@@ -224,7 +236,7 @@ def main():
         pf, mf = get_max_preds_hrnet(of)
         fx.update(eval_argmax_xy=pe, eval_maxvals=me, eval_sample=oe.reshape(-1)[::64].copy(),
                   flip_argmax_xy=pf, flip_maxvals=mf, flip_sample=of.reshape(-1)[::64].copy())
-        np.savez_compressed(os.path.join(HERE, f"g3_w32_{tag}.npz"), **fx)
+        np.savez_compressed(os.path.join(OUT, f"g3_w32_{tag}.npz"), **fx)
         print("G3", tag, "loss", loss.item(), "absmax", np.abs(o).max())
 
     # ---- G8: W48 key list / param count / output stats
@@ -235,13 +247,13 @@ def main():
         o = m(torch.from_numpy(img)).numpy()
     keys = list(m.state_dict().keys())
     shapes = [tuple(v.shape) for v in m.state_dict().values()]
-    np.savez_compressed(os.path.join(HERE, "g8_w48.npz"), nparams=sum(p.numel() for p in m.parameters()),
+    np.savez_compressed(os.path.join(OUT, "g8_w48.npz"), nparams=sum(p.numel() for p in m.parameters()),
                         nkeys=len(keys), out_sample=o.reshape(-1)[::16].copy(), out_mean=o.mean(), out_std=o.std(),
                         key_crc=np.array([__import__("zlib").crc32((k + str(s)).encode()) for k, s in zip(keys, shapes)]))
     m32 = _ref_model(tmp, "w32")
     keys32 = list(m32.state_dict().keys())
     shapes32 = [tuple(v.shape) for v in m32.state_dict().values()]
-    with open(os.path.join(HERE, "g8_w32_keys.txt"), "w") as f:
+    with open(os.path.join(OUT, "g8_w32_keys.txt"), "w") as f:
         for k, s in zip(keys32, shapes32):
             f.write(f"{k} {'x'.join(map(str, s))}\n")
     print("G8 w48 params", sum(p.numel() for p in m.parameters()), "w32 keys", len(keys32))
@@ -259,7 +271,7 @@ def main():
         l.backward()
         g6.update({f"{name}_o": o, f"{name}_t": t, f"{name}_w": w, f"{name}_loss": np.float64(l.item()),
                    f"{name}_grad": ot.grad.numpy()})
-    np.savez_compressed(os.path.join(HERE, "g6_mse.npz"), **g6)
+    np.savez_compressed(os.path.join(OUT, "g6_mse.npz"), **g6)
 
     # ---- G7: get_max_preds_hrnet incl. ties and all-negative maps; final preds; flip_back; oks_nms
     hm = rng.standard_normal((3, 17, 16, 12)).astype(np.float32)
@@ -280,19 +292,17 @@ def main():
     ar = 4000 + 2000 * rng.random(6)
     db = [dict(keypoints=kp[i], score=sc[i], area=ar[i]) for i in range(6)]
     keep = {f"keep_{str(t).replace('.', '')}": np.array(oks_nms(db, t)) for t in (0.9, 0.5)}
-    np.savez_compressed(os.path.join(HERE, "g7_decode.npz"), hm=hm, preds=p, maxvals=mv, center=center, scale=scale,
+    np.savez_compressed(os.path.join(OUT, "g7_decode.npz"), hm=hm, preds=p, maxvals=mv, center=center, scale=scale,
                         final_preds=fp, final_coords=fcoords, flip_back=fb, nms_kpts=kp, nms_scores=sc,
                         nms_areas=ar, **keep)
-    print("G6/G7 done; fixtures in", HERE)
+    print("G6/G7 done; fixtures in", OUT)
 
 
 def gen_g9():
     """G9: JointsDataset.generate_target (data/JointsDataset.py:230-286) called on the reference's own
     class (file loaded directly: data/__init__.py pulls in pycocotools) with a stand-in `self`."""
     import importlib.util
-    tmp = tempfile.mkdtemp()
-    if "CONFIG" not in sys.modules:
-        _install_shims(tmp)
+    tmp = _shim_dir()
     spec = importlib.util.spec_from_file_location("ref_joints_dataset", os.path.join(REF, "data", "JointsDataset.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
@@ -313,7 +323,7 @@ def gen_g9():
         tg, tw = zip(*[mod.JointsDataset.generate_target(me, joints[b], vis[b]) for b in range(B)])
         out.update({f"{tag}_joints": joints, f"{tag}_vis": vis, f"{tag}_target": np.stack(tg), f"{tag}_tw": np.stack(tw),
                     f"{tag}_cfg": np.array([sigma, *hm, *img], np.float64)})
-    np.savez_compressed(os.path.join(HERE, "g9_targets.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "g9_targets.npz"), **out)
     print("G9 done")
 
 
@@ -321,9 +331,7 @@ def gen_g8_train():
     """G8b: HRNet-W48 TRAINING step from the reference (bs 2, 128x96): output sample, loss, the L2 norm of
     every parameter gradient, a set of full gradients (the 48/96/192/384 widths exercise the ragged
     channel-chunk paths of every kernel) and BatchNorm buffers after the step."""
-    tmp = tempfile.mkdtemp(prefix="stl_golden_")
-    if "CONFIG" not in sys.modules:
-        _install_shims(tmp)
+    tmp = _shim_dir()
     from lib.loss import PersonMSELoss
     m = _ref_model(tmp, "w48")
     m.train()
@@ -342,7 +350,7 @@ def gen_g8_train():
             fx["grad/" + k] = p_.grad.numpy().astype(np.float32)
             nfull += 1
     fx["buffernorm_all"] = np.array([float(v.double().norm()) for _, v in m.named_buffers()])
-    np.savez_compressed(os.path.join(HERE, "g8_w48_train.npz"), **fx)
+    np.savez_compressed(os.path.join(OUT, "g8_w48_train.npz"), **fx)
     print("G8b w48 train loss", loss.item(), "full grads", nfull)
 
 
@@ -353,9 +361,7 @@ def gen_g10():
     as plain torch.nn layers (the third-party part that stays restated), loaded with
     oracle.vgg_ref.synth_vgg_weights() instead of the ImageNet download."""
     from oracle import vgg_ref
-    tmp = tempfile.mkdtemp(prefix="stl_golden_")
-    if "CONFIG" not in sys.modules:
-        _install_shims(tmp)
+    tmp = _shim_dir()
     import torch.nn as nn
 
     def vgg16(pretrained=False, **kw):
@@ -392,7 +398,7 @@ def gen_g10():
             l = mod(torch.from_numpy(a), torch.from_numpy(b))
             fx[f"{tag}_in"], fx[f"{tag}_tg"], fx[f"{tag}_loss"], fx[f"{tag}_resize"] = a, b, np.float64(l.item()), np.int64(resize)
             print("G10", tag, shape, "resize", resize, "loss", l.item())
-    np.savez_compressed(os.path.join(HERE, "g10_vgg.npz"), **fx)
+    np.savez_compressed(os.path.join(OUT, "g10_vgg.npz"), **fx)
 
 
 def gen_g12():
@@ -402,9 +408,7 @@ def gen_g12():
     called here do not touch them.  ``accuracy`` itself cannot run (line :355-356 indexes a 1-D array with a
     4-tuple); acc/avg/cnt below are the reference's own get_max_preds_hrnet + calc_dists + dist_acc composed
     by the loop of :353-362 with that line read as ``acc[i + 1] = dist_acc(dists[idx[i]])``."""
-    tmp = tempfile.mkdtemp(prefix="stl_golden_")
-    if "CONFIG" not in sys.modules:
-        _install_shims(tmp)
+    tmp = _shim_dir()
     for name in ("pycocotools", "pycocotools.coco", "pycocotools.cocoeval", "data", "data.data_processing",
                  "lib.utils", "lib.bounding_box"):
         if name not in sys.modules:
@@ -468,7 +472,7 @@ def gen_g12():
               sub_kept_scores=np.concatenate([[p_["score"] for p_ in g] for g in kept]),
               sub_kept_kpts=np.concatenate([np.stack([p_["keypoints"] for p_ in g]) for g in kept]),
               sub_kept_img=np.concatenate([[p_["image"] for p_ in g] for g in kept]))
-    np.savez_compressed(os.path.join(HERE, "g12_metrics.npz"), **fx)
+    np.savez_compressed(os.path.join(OUT, "g12_metrics.npz"), **fx)
     print("G12 avg_acc", avg, "cnt", cnt, "kept per image", [len(g) for g in kept])
 
 
@@ -476,9 +480,7 @@ def gen_g11():
     """G11: the reference's transform arithmetic for the crop / flip augmentation (lib/transforms.py:167-250):
     get_affine_transform (cv2.getAffineTransform replaced by the exact 3-point solve, as in main()),
     affine_transform and fliplr_joints on seeded persons -- forward and inverse matrices, transformed joints."""
-    tmp = tempfile.mkdtemp(prefix="stl_golden_")
-    if "CONFIG" not in sys.modules:
-        _install_shims(tmp)
+    tmp = _shim_dir()
     import lib.transforms as ref_tf
 
     def _get_affine(src, dst):
@@ -531,7 +533,7 @@ def gen_g11():
     np.random.seed(77)
     c, s = mod.JointsDataset.half_body_transform(me, joints[0].copy(), vis_few)
     fx.update(hb_center=np.stack(hb_c), hb_scale=np.stack(hb_s), hb_ok=np.array(hb_ok), hb_few_none=np.array(c is None and s is None))
-    np.savez_compressed(os.path.join(HERE, "g11_affine.npz"), **fx)
+    np.savez_compressed(os.path.join(OUT, "g11_affine.npz"), **fx)
     print("G11 done", fx["trans_0"][2], "half-body ok", hb_ok)
 
 

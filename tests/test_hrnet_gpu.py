@@ -176,7 +176,7 @@ def test_w32_mixed_vs_reference_golden(golden_dir, tag, hw, sigma):
     vals = np.array([np.sqrt(gn[k]) for k in g["gradnorm_keys"]])
     _diag(f"diag_w32_mixed_{tag}.txt", [f"out rel err {err:.3e}", f"argmax agreement {agree:.3f}", f"loss {loss.item()} ref {float(g['loss'])}",
                                         "gradnorm " + " ".join(f"{k}:{v:.4e}/{r:.4e}" for k, v, r in zip(g["gradnorm_keys"], vals, g["gradnorm_vals"]))])
-    assert err < 1.2e-2, f"mixed-mode output error {err:.3e}"
+    assert err < 8e-3, f"mixed-mode output error {err:.3e}"   # measured 4.5e-3 / 5.8e-3
     assert agree >= 0.85, f"argmax agreement {agree:.3f} (random-weight heat maps have near-ties)"
     assert abs(loss.item() - float(g["loss"])) < 2e-4 * float(g["loss"])
     np.testing.assert_allclose(vals, g["gradnorm_vals"], rtol=5e-2)   # gradients are bf16 like in the pure mode

@@ -196,3 +196,27 @@ def test_vgg_oracle_vs_reference_perceptual_loss(golden_dir):
             l = vgg_ref.vgg_perceptual_loss(torch.from_numpy(g[f"{tag}_in"]), torch.from_numpy(g[f"{tag}_tg"]), w,
                                             resize=bool(g[f"{tag}_resize"]))
         assert abs(float(l) - float(g[f"{tag}_loss"])) <= 1e-5 * float(g[f"{tag}_loss"]), tag
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference tree exists in the build container only")
+def test_golden_generator_reproduces_every_committed_fixture(tmp_path):
+    """`python tests/golden/make_golden.py` (no argument, as documented) must reproduce all twelve .npz fixtures and the key list
+    bit for bit -- the pin has to be regenerable by the documented command.  (Until round 4 the all-in-one run wrote a W32 net
+    into g8_w48_train.npz: every gen_* made a new temp dir but the reference's CONFIG kept pointing at main()'s.)"""
+    import glob
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STL_GOLDEN_OUT=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
+    subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "make_golden.py")], check=True, env=env, cwd=root,
+                   stdout=subprocess.DEVNULL, timeout=900)
+    committed = sorted(glob.glob(os.path.join(root, "tests", "golden", "*.npz")))
+    assert len(committed) == 12
+    for f in committed:
+        a, b = np.load(f), np.load(os.path.join(str(tmp_path), os.path.basename(f)))
+        assert sorted(a.files) == sorted(b.files), f
+        for k in a.files:
+            assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype, (f, k)
+            assert np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"), f"{os.path.basename(f)}[{k}] differs from the reference's output"
+    assert open(os.path.join(root, "tests", "golden", "g8_w32_keys.txt")).read() == open(os.path.join(str(tmp_path), "g8_w32_keys.txt")).read()
+    assert not glob.glob("/root/reference/**/__pycache__", recursive=True), "the generator wrote bytecode into the reference tree"

@@ -101,7 +101,7 @@ def test_w32_b32_fp32_train_step_vs_oracle(oracle_b32):
     assert abs(loss.item() - r["loss"]) < 1e-3 * abs(r["loss"])
     assert rel.max() < 5e-3, f"worst gradient norm {names[worst[0]]}: rel {rel.max():.3e}"
     # Element-wise bar at B = 32: the fp32 ORACLE itself is only this close to the exact gradient here -- run in
-    # fp64 (tests/diag/diag_fp64.py -> profiles/r02_b32_fp32_grad_rounding.txt) torch-fp32 deviates by up to 1.7e-2 of
+    # fp64 (tools/diag/diag_fp64.py -> profiles/r02_b32_fp32_grad_rounding.txt) torch-fp32 deviates by up to 1.7e-2 of
     # the largest element (batch-32 gradients are sums of cancelling terms through ~50 BatchNorm backwards), the
     # HIP fp32 path by up to 2.1e-2.  At bs 2 the same comparison holds 5e-3 (test_hrnet_gpu.py).  A wrong tap,
     # channel or split-K slab shows up as a direction error, hence the cosine bar on every tensor.
@@ -286,7 +286,7 @@ def test_three_train_steps_vs_oracle_and_torch_optim(opt):
             den += float(du_ref.pow(2).sum())
     rel = (num / den) ** 0.5
     # 6 %: one ReLU whose pre-activation sits within fp32 rounding of zero on opposite sides in the two implementations
-    # changes the gradients upstream of it by ~1e-2 of their largest element (tests/diag/diag_tiny_bwd.py tiny 300: such a
+    # changes the gradients upstream of it by ~1e-2 of their largest element (tools/diag/diag_tiny_bwd.py tiny 300: such a
     # flip at stage4.0.branches.0.1 on the first of these batches; torch fp32 vs fp64 shows the same kind of event at
     # layer1.1 on another batch, profiles/r02_fp32_layerwise_vs_fp64.txt).  A stale weight layout or a wrong optimiser
     # order moves the per-step losses above by percent, not 1e-3.

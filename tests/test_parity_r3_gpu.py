@@ -101,8 +101,10 @@ def trained_b32():
         out = ref(torch.from_numpy(img)).numpy()
         with hrnet_ref.bf16_storage(ref):
             out_emul = ref(torch.from_numpy(img)).numpy()
+        with hrnet_ref.f16_storage(ref):
+            out_emul_f16 = ref(torch.from_numpy(img)).numpy()
     del ref
-    return dict(img=img, tgt=tgt, tw=tw, sd=sd, out=out, out_emul=out_emul, hist=hist)
+    return dict(img=img, tgt=tgt, tw=tw, sd=sd, out=out, out_emul=out_emul, out_emul_f16=out_emul_f16, hist=hist)
 
 
 def test_w32_b32_bf16_on_trained_weights_vs_oracle(trained_b32):
@@ -180,20 +182,30 @@ def test_w32_b32_mixed_on_trained_weights_vs_oracle(trained_b32):
     with torch.no_grad():
         out = m(torch.from_numpy(r["img"]).cuda())
     torch.cuda.synchronize()
-    o, ref = out.detach().cpu().numpy(), r["out"]
+    ref = r["out"]
     absmax = float(np.abs(ref).max())
-    ae = np.abs(o - ref).reshape(-1) / absmax
-    err, q999, rms = float(ae.max()), float(np.quantile(ae, 0.999)), float(np.sqrt(np.mean(ae ** 2)))
-    p, _ = get_max_preds_hrnet(o)
     pr, _ = pose_ref.get_max_preds(ref)
-    disp = np.abs(p - pr).max(-1)
-    n_same, n_far = int((disp == 0).sum()), int((disp > 1).sum())
-    acc_m, acc_r = pose_ref.pck_accuracy(o, r["tgt"]), pose_ref.pck_accuracy(ref, r["tgt"])
-    _diag("diag_w32_b32_mixed_trained.txt", [f"out rel err: max {err:.3e} / 99.9 % {q999:.3e} / rms {rms:.3e}", f"argmax kept {n_same}/{disp.size}, moved > 1 px: {n_far}",
-                                             f"PCK mixed {acc_m[1]:.6f} oracle {acc_r[1]:.6f}"])
-    assert rms < 1.5e-3 and q999 < 8e-3 and err < 1e-1, (err, q999, rms)
-    assert n_same >= 490 and n_far <= 16, (n_same, n_far)
-    assert abs(acc_m[1] - acc_r[1]) <= 8.0 / disp.size + 1e-12
+    acc_r = pose_ref.pck_accuracy(ref, r["tgt"])
+
+    def figures(o, decode):
+        ae = np.abs(o - ref).reshape(-1) / absmax
+        p, _ = decode(o)
+        disp = np.abs(p - pr).max(-1)
+        return dict(err=float(ae.max()), q999=float(np.quantile(ae, 0.999)), rms=float(np.sqrt(np.mean(ae ** 2))),
+                    same=int((disp == 0).sum()), far=int((disp > 1).sum()), n=disp.size, pck=pose_ref.pck_accuracy(o, r["tgt"])[1])
+    hip, emu = figures(out.detach().cpu().numpy(), get_max_preds_hrnet), figures(r["out_emul_f16"], pose_ref.get_max_preds)
+    _diag("diag_w32_b32_mixed_trained.txt",
+          [f"{tag}: out rel err max {f['err']:.3e} / 99.9 % {f['q999']:.3e} / rms {f['rms']:.3e}; argmax kept {f['same']}/{f['n']}, moved > 1 px: {f['far']}; "
+           f"PCK {f['pck']:.6f} (oracle {acc_r[1]:.6f})" for tag, f in (("HIP mixed", hip), ("oracle with f16 storage", emu))])
+    # Bars = what was measured in round 4 (HIP 4.6e-2 / 3.9e-3 / 7.7e-4, 518 kept, 8 moved; the f16-storage oracle 5.3e-2 / 3.9e-3 /
+    # 7.7e-4, 514, 7) with ~1.3x headroom for the fitting run's own variation -- and the EMULATION must pass them too: they
+    # describe what f16 storage at these points costs, not this implementation.
+    for tag, f in (("HIP mixed", hip), ("oracle with f16 storage", emu)):
+        assert f["rms"] < 1e-3 and f["q999"] < 5e-3 and f["err"] < 7e-2, (tag, f)
+        assert f["same"] >= 505 and f["far"] <= 11, (tag, f)
+        assert abs(f["pck"] - acc_r[1]) <= 8.0 / f["n"] + 1e-12, (tag, f)
+    # and the HIP path is no further from the fp32 oracle than the emulation by more than a quarter
+    assert hip["rms"] <= 1.25 * emu["rms"] and hip["q999"] <= 1.25 * emu["q999"], (hip, emu)
 
 
 # ------------------------------------------------------------------------------------------------ fp32 gradients vs fp64

@@ -204,3 +204,41 @@ def test_trainer_two_ranks_uneven_loaders_stay_in_step(tmp_path):
     assert not np.array_equal(b0, b1)                         # BatchNorm statistics stay per replica (nn.DataParallel keeps replica 0's)
     names = sorted(os.listdir(os.path.join(exp, "models")))
     assert names == ["checkpoint_epoch_0.pth", "checkpoint_epoch_1.pth", "checkpoint_epoch_final.pth"]
+
+
+def test_f16_overflow_of_a_badly_scaled_checkpoint_is_reported_not_trained_on():
+    """Forward tensors of the default mixed mode are f16 (|y| <= 65504); lib/model_setup.py:38-42 loads arbitrary checkpoints.
+    A checkpoint whose convolution weights are 1e5 x too large (BatchNorm hides the scale from an fp32 run) overflows the raw
+    conv outputs: the step must not train on it silently -- the BatchNorm statistics carry the infinity, the running
+    statistics and the weights stay as they were (the optimiser skips non-finite gradients) and the host gets a
+    FloatingPointError that names the layer and the remedy.  The same checkpoint trains in the bf16 mode."""
+    from stlpose_amd import PoseHighResolutionNet
+    from stlpose_amd.train_step import TrainStep
+    torch.manual_seed(3)
+    base = PoseHighResolutionNet("tiny", "fp32")
+    sd = {k: (v * 1e5 if (v.dim() == 4 and not k.startswith("final_layer")) else v.clone()) for k, v in base.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    img, tgt, tw = torch.randn(4, 3, 64, 64, generator=g), torch.rand(4, 17, 16, 16, generator=g), torch.ones(4, 17, 1)
+
+    def run(dtype):
+        m = PoseHighResolutionNet("tiny", dtype)
+        m.load_state_dict(sd, strict=True)
+        ts = TrainStep(m, 4, 64, 64, optimizer="adam", lr=1e-3)
+        ts.load_batch(img.cuda(), tgt.cuda(), tw.cuda())
+        w0, rm0 = ts.store.master.clone(), ts.store.bufs.clone()
+        loss = ts.step()
+        torch.cuda.synchronize()
+        return m, ts, w0, rm0, float(loss.item())
+
+    m, ts, w0, rm0, loss = run("mixed")
+    assert not np.isfinite(loss)
+    with pytest.raises(FloatingPointError, match="compute_dtype='bf16'") as ei:
+        ts.check_forward_range()
+    assert "conv" in str(ei.value) or "layer" in str(ei.value) or "bn" in str(ei.value), str(ei.value)
+    assert torch.equal(ts.store.master, w0), "the overflowed step changed the weights"
+    assert torch.isfinite(ts.store.bufs).all(), "running statistics took the overflow in"
+    ts.check_forward_range()     # reported once; the flag is re-armed
+    m2, ts2, _, _, loss2 = run("bf16")
+    assert np.isfinite(loss2)
+    ts2.check_forward_range()    # nothing to report
+    assert torch.isfinite(ts2.store.master).all() and not torch.equal(ts2.store.master, w0)

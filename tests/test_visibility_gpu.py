@@ -89,11 +89,10 @@ def _fixed_batch(Bn, H, W, seed=0):
     return img, tgt, tw
 
 
-# (dtype, replays, bar on the worst gradient deviation relative to the largest gradient element).  fp32: only the order of the
-# fp64 statistics atomics varies between replays.  mixed: a BatchNorm constant that moves by one fp32 ulp can flip the f16 / bf16
-# rounding of single activations, so the bar is the measured noise floor times a margin, still orders of magnitude below what a
-# stale or half-written tensor does (O(1)).
-REPLAY_CASES = [("fp32", max(1, N_STEPS // 3), 1e-5), ("mixed", N_STEPS, 1e-3)]
+# (dtype, replays, bar on the worst gradient deviation relative to the largest gradient element).  Only the order of the fp64
+# statistics atomics varies between replays (the weight-gradient slabs are summed in a fixed order); what a stale or half-written
+# tensor does is O(1).
+REPLAY_CASES = [("fp32", max(1, N_STEPS // 3), 1e-6), ("mixed", N_STEPS, 1e-5)]   # measured on MI355X: exactly 0 in all four cases
 
 
 @pytest.mark.parametrize("fence", ["device", "system"])

@@ -18,5 +18,5 @@ for pg in (None, dist.group.WORLD):
     for _ in range(30): ts.step()
     torch.cuda.synchronize()
     print("dp" if pg is not None else "single", f"{(time.perf_counter() - t0) / 30 * 1e3:.3f} ms/step", flush=True)
-    m._pinned_by = None
+    del ts   # the weak reference (hrnet._holder) releases the model for the next TrainStep
 dist.destroy_process_group()
