@@ -176,9 +176,17 @@ __device__ __forceinline__ float rsqrt_nr(float x) {
     return r * (1.5f - 0.5f * x * r * r);
 }
 
+// a, b of y -> a * y + b for a BatchNorm given mean and 1 / std (the ReLU-mask BatchNorm of a data gradient's epilogue)
+__device__ __forceinline__ void bn_affine(float gamma, float beta, float mean, float rstd, float& a, float& b) {
+#pragma clang fp contract(off)   // (as below)
+    a = gamma * rstd;
+    b = beta - mean * a;
+}
+
 // ---------------------------------------------------------------- per-channel constants of an stl_src
 // ca/cb/cc: v = ca*x + cb (BN) or v = ca*dt + cb*y + cc (BNBWD).  mu/rs: mean and 1/std (for yhat).
 __device__ __forceinline__ void bn_mean_rstd(const stl_src& s, int c, int C, float& mean, float& rstd) {
+#pragma clang fp contract(off)   // per-channel constants: the same roundings in every kernel that derives them (no fused multiply-add here or there)
     if (s.stats) {
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -198,6 +206,7 @@ __device__ __forceinline__ void bn_mean_rstd(const stl_src& s, int c, int C, flo
 }
 
 __device__ __forceinline__ void src_consts(const stl_src& s, int c, int C, float& ca, float& cb, float& cc) {
+#pragma clang fp contract(off)   // per-channel constants: the same roundings in every kernel that derives them (no fused multiply-add here or there)
     if (s.mode == STL_SRC_PLAIN) {
         ca = 1.f, cb = 0.f, cc = 0.f;
         return;
@@ -247,6 +256,7 @@ __device__ __forceinline__ void bn_raw_load(const stl_src& s, int c, int C, SrcR
     }
 }
 __device__ __forceinline__ void bn_raw_finish(const stl_src& s, const SrcRaw& r, float& mean, float& rstd) {
+#pragma clang fp contract(off)   // per-channel constants: the same roundings in every kernel that derives them (no fused multiply-add here or there)
     if (s.stats) {
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -275,6 +285,7 @@ __device__ __forceinline__ void src_raw_load(const stl_src& s, int c, int C, Src
     }
 }
 __device__ __forceinline__ void src_raw_finish(const stl_src& s, const SrcRaw& r, float& ca, float& cb, float& cc) {
+#pragma clang fp contract(off)   // per-channel constants: the same roundings in every kernel that derives them (no fused multiply-add here or there)
     if (s.mode == STL_SRC_PLAIN) {
         ca = 1.f, cb = 0.f, cc = 0.f;
         return;

@@ -164,8 +164,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
             float a = 0.f, b = 0.f, mu = 0.f, rs = 0.f;
             if (n0 + c < p.Co) {
                 bn_mean_rstd(p.mask_bn, n0 + c, p.Co, mu, rs);
-                a = p.mask_bn.gamma[n0 + c] * rs;
-                b = p.mask_bn.beta[n0 + c] - mu * a;
+                bn_affine(p.mask_bn.gamma[n0 + c], p.mask_bn.beta[n0 + c], mu, rs, a, b);
             }
             cm[c] = a, cm[BCO + c] = b, cm[2 * BCO + c] = mu, cm[3 * BCO + c] = rs;
         }
@@ -658,6 +657,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_core_kernel(const Conv
 
 #include "conv_ws.inc"
 #include "conv1x1.inc"
+#include "conv_r2.inc"
 
 template <typename T, typename TY, int KS, int WM, int WN, int MT, int NTW, int NVA, bool Q, bool PE, int OCC = 1, int WR = -1, bool ZM = false, bool DB = false, int EO = -1>
 int launch(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
@@ -681,6 +681,10 @@ int launch(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
 //                             once per 512 pixels instead of once per 128: 105.8 -> 71.8 us)
 //   2 = 256 x 64, 8 waves  -- C >= 64 layers whose K is one chunk, 1x1 convolutions on that block, the block-end (BNADD) source
 //   3 = 256 x 64, 8 waves, two LDS images, one barrier per stage -- the C >= 64 3x3 layers (forward and data gradient; round 4)
+//   5 = 256 x 64, 8 waves, <= 128 VGPRs and <= 76 KB of LDS: TWO PER CU (conv_r2.inc, round 5: filters by LDS-DMA, planar halo image) --
+//       the C >= 64 3x3 stride-1 forward convolutions of the 16-bit modes; launches it has no instantiation for fall back to shape 3
+//   6 = 128 x 64, 8 waves, the same kernel with two pixel tiles per wave -- their data gradients (a second source tensor and up
+//       to three epilogue operands beside 32 accumulators do not fit 128 registers; with 16 they do); fallback: shape 0
 //   4 = 128 x 32, 4 waves  -- C <= 32 fallback where no 256-pixel tile fits (<= 128 VGPRs, <= 40 KB LDS: four blocks per CU)
 //   7 = 128 x 64, wave-specialised (4 loader + 4 compute waves, double-buffered LDS image) -- stride-2 convolutions
 //   8 = 256 x 32, 8 waves  -- the C <= 32 3x3 layers (two 128-pixel halves share one filter copy and one halo tile)
@@ -688,13 +692,13 @@ int launch(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
 // (256 x 128 and the wave-specialised 512 x 32 / 256 x 64 blocks -- ids 5 / 6 -- lost end to end in rounds 2 and 3 and were removed.)
 struct Shape {
     int px, co, thr;   // pixels / output channels per block, threads
-    int ws;            // 1: wave-specialised kernel (4 loader + 4 compute waves, double-buffered LDS); 2: uniform kernel, two LDS images
+    int ws;            // 1: wave-specialised kernel (4 loader + 4 compute waves, double-buffered LDS); 2: uniform kernel, two LDS images; 3: conv_r2
     int lthr, nva_max; // threads that stage the halo, max staging vectors per such thread
 };
 constexpr int NSHAPES = 10;
 constexpr Shape SHAPES[NSHAPES] = {{128, 64, 256, 0, 256, 9}, {512, 32, 512, 0, 512, 6}, {256, 64, 512, 0, 512, 3},
                                    {256, 64, 512, 2, 512, 3}, {128, 32, 256, 0, 256, 6},
-                                   {0, 0, 0, 0, 1, 0}, {0, 0, 0, 0, 1, 0}, {128, 64, 512, 1, 256, 9},
+                                   {256, 64, 512, 3, 512, 3}, {128, 64, 512, 3, 512, 2}, {128, 64, 512, 1, 256, 9},
                                    {256, 32, 512, 0, 512, 3}, {128, 32, 512, 1, 256, 3}};
 
 // EO >= 0 (data gradients whose operand set the planner emits in bulk): own instantiations of the C >= 64 3x3 block (the
@@ -743,7 +747,7 @@ int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStrea
 // block-end source (STL_SRC_BNADD): the shapes the two-conv units of the network are planned with -- 256 px x 32 co
 // (C <= 32), 256 px x 64 co (C = 64 / 128) and their small-map fallbacks; own instantiations, so that the
 // data-gradient kernels (Q without ZM) carry none of this
-static bool bnadd_shape_ok(int shape, int nva) { return nva <= 3 && (shape == 0 || shape == 2 || shape == 3 || shape == 4 || shape == 8); }
+static bool bnadd_shape_ok(int shape, int nva) { return nva <= 3 && (shape == 0 || shape == 2 || shape == 3 || shape == 4 || shape == 5 || shape == 6 || shape == 8); }
 template <typename T>
 int dispatch_bnadd(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     if (nva <= 3) switch (shape) {
@@ -767,6 +771,10 @@ int conv_backend(int path, const stl_conv& p, const ConvK& k, int shape, int nva
     }
     constexpr bool FWD = std::is_same<T, TY>::value, BWD = !std::is_same<T, f16>::value;
     if (path == 0) return run_1x1<T, TY>(p, st);
+    if (path == 3) {
+        if constexpr (sizeof(T) == 2) return dispatch_r2<T, TY>(p, k, shape == 5 ? 4 : 2, grid, lds, st);
+        return stl_set_error("conv_r2: 16-bit element types only");
+    }
     if (path == 1) {
         if constexpr (FWD) return dispatch_bnadd<T>(shape, nva, k, grid, lds, st);
     }
@@ -809,6 +817,23 @@ size_t lds_bytes(const stl_conv& p, int shape, int TH, int TW, int ck, ConvK* ou
     const int HR = (TH - 1) * seff + p.ks, HC = (TW - 1) * seff + p.ks;
     const int nchunks = ceil_div(p.Ci, ck), cipad = nchunks * ck;
     const int bco = SHAPES[shape].co, ws = SHAPES[shape].ws;
+    if (ws == 3) {   // conv_r2: [cs | cm | two halo planes of 32 B per pixel | unpadded filter image | per-tile sums]
+        int off = 3 * cipad * 4;
+        const int off_cm = off;
+        off = (off + 4 * bco * 4 + 15) & ~15;
+        const int off_a = off, pl = ((HR * HC * R2_PS) + 15) & ~15;
+        off += 2 * pl;
+        const int off_b = (off + 1023) & ~1023;   // 1-KB DMA pieces
+        off = off_b + bco * R2_ROWF;
+        const int off_red = off;
+        off += 4 * 2 * bco * 4;
+        if (out) {
+            out->HR = HR, out->HC = HC, out->HP = HR * HC, out->nchunks = nchunks, out->cipad = cipad;
+            out->off_cs = 0, out->off_cm = off_cm, out->off_a = off_a, out->off_b = off_b, out->off_red = off_red;
+            out->sz_a = pl, out->sz_b = 0, out->wres = 0;
+        }
+        return (size_t)off;
+    }
     int off = 3 * cipad * 4;
     const int off_cm = off;
     off += 4 * bco * 4;
@@ -855,10 +880,16 @@ Plan choose_plan(const stl_conv& p, int ck) {
         if (want_ws && shape != (deep_small ? 9 : 7)) continue;
         // two LDS images (shape 3) wherever the 256 x 64 block walks K in more than one chunk: the staging of chunk c + 1
         // hides behind the MFMAs of chunk c.  STL_CONV_DB=0: the single-image kernel everywhere (A/B).
-        if (shape == 2 || shape == 3) {
+        if (shape == 2 || shape == 3 || shape == 5 || shape == 6) {
             static const bool db_on = !(getenv("STL_CONV_DB") && atoi(getenv("STL_CONV_DB")) == 0);
+            // STL_CONV_R2 (A/B): bit 0 forward convolutions, bit 1 data gradients on the two-per-CU kernel (else the one-per-CU
+            // two-image block, shape 3); bit 2: forward convolutions on its 128-pixel form as well.  Default 3.
+            const int r2_mode = getenv("STL_CONV_R2") ? atoi(getenv("STL_CONV_R2")) : 3;   // (read per plan: plans are made once per layer)
             const bool db = db_on && p.ks == 3 && p.stride == 1 && p.Ci > ck;
-            if ((shape == 3) != db) continue;
+            const bool dgrad = p.src.mode == STL_SRC_BNBWD;   // (the planner sets the source before it asks for a plan)
+            const bool r2 = db && (r2_mode & (dgrad ? 2 : 1)) && p.dtype != STL_F32 && p.Ci % 32 == 0 && p.Ci >= 64;
+            const int want = r2 ? ((dgrad || (r2_mode & 4)) ? 6 : 5) : (db ? 3 : 2);
+            if (shape != want) continue;
         }
         if ((shape == 1 || shape == 8) && p.Co > 32) continue;
         if ((shape == 4 || shape == 8) && !c32) continue;
@@ -876,6 +907,7 @@ Plan choose_plan(const stl_conv& p, int ck) {
             const size_t lds = lds_bytes(p, shape, th, tw, ck, nullptr);
             if (shape == 4 && lds > 40 * 1024 && nva <= 3) continue;  // keep four blocks per CU
             if (shape == 8 && lds > 80 * 1024) continue;              // ... resp. two 8-wave blocks
+            if ((shape == 5 || shape == 6) && lds > 76 * 1024) continue;   // two per CU in mixed company
             if (lds > 158 * 1024) continue;
             const double tiles = (double)ceil_div(vrows, th) * ceil_div(p.Wo, tw);
             // cost model (arbitrary units): MFMA work of all launched tiles (padding included), the
@@ -887,6 +919,7 @@ Plan choose_plan(const stl_conv& p, int ck) {
             const double waves = blocks * sh.thr / 64.0;
             if (waves < 2048.0) cost *= 1.0 + 0.15 * (2048.0 / waves - 1.0 > 4.0 ? 4.0 : 2048.0 / waves - 1.0);
             if (c32 && shape == 4) cost *= 4.0;   // fallback only
+            if (shape == 5 || shape == 6) cost *= 0.98;   // wins ties against the four-wave 128 x 64 block (small problems: both at the wave-count penalty's cap)
             if (cost < best.cost) best = Plan{shape, th, tw, lds, cost};
         }
     }
@@ -994,6 +1027,9 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
         plan = choose_plan(p, ck);
         STL_CHECK(plan.shape >= 0, "conv: no tile fits LDS for %dx%d ks %d stride %d Ci %d", p.Ho, p.Wo, p.ks, p.stride, p.Ci);
     }
+    // an operand set / source conv_r2 has no instantiation for: conv_core_kernel's block of the same pixel count, same tile
+    if (plan.shape == 5 && !r2_takes(p, 4)) plan.shape = 3;
+    if (plan.shape == 6 && !r2_takes(p, 2)) plan.shape = 0;
     {
         const Shape shp = SHAPES[plan.shape];
         const int nv = ceil_div(((plan.TH - 1) * p.stride + p.ks) * ((plan.TW - 1) * p.stride + p.ks) * 4, shp.lthr);
@@ -1033,6 +1069,8 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     // (16.62 -> 16.56 ms per step in round 2); 384 for the 8-wave 256 px x 32 co shape (two blocks per CU on half the CUs)
     int cap = sh.thr == 512 ? 256 : 768;
     if (plan.shape == 8) cap = 384;
+    if (plan.shape == 5) cap = 512;   // two per CU
+    if (plan.shape == 6) cap = 768;   // three per CU (<= 55 KB of LDS, <= 128 VGPRs)
     cap = std::max(8, (cap / k.ny + 7) / 8 * 8);
     if (const char* e = getenv("STL_CONV_GRID_CAP")) cap = atoi(e) > 0 ? (atoi(e) + 7) / 8 * 8 : cap;   // tools/conv_probe.py
     if (gx > cap) gx = cap;
@@ -1042,6 +1080,6 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
         fprintf(stderr, "[stl conv] %dx%d Ci%d Co%d ks%d s%d: shape=%d tile=%dx%d npt=%d grid=(%d x %d) lds=%zu nva=%d nchunks=%d\n", p.Ho,
                 p.Wo, p.Ci, p.Co, p.ks, p.stride, plan.shape, plan.TH, plan.TW, k.npt, gx, k.ny, lds, nva, k.nchunks);
     hipStream_t st = (hipStream_t)stream;
-    return backend(zm ? 1 : 2, p, k, plan.shape, nva, grid, lds, st);
+    return backend((plan.shape == 5 || plan.shape == 6) ? 3 : (zm ? 1 : 2), p, k, plan.shape, nva, grid, lds, st);
 }
 #endif   // STL_HAS_BF16

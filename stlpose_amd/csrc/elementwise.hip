@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(const stl_fuse p) {
             if (tm.src.mode == STL_SRC_BN) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float u = cs[(t * 2) * C + c0 + j] * f[j] + cs[(t * 2 + 1) * C + c0 + j];
+                    float u = fmaf(cs[(t * 2) * C + c0 + j], f[j], cs[(t * 2 + 1) * C + c0 + j]);   // one rounding, as conv_common.inc's fma2
                     // BN terms are rounded to the storage type like a materialised BN output would be
                     f[j] = tm.src.relu ? fmaxf(u, 0.f) : u;
                 }

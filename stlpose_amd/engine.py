@@ -523,8 +523,8 @@ class Engine:
                 d.Ho, d.Wo, d.Co = x.H, x.W, x.C
                 d.ks, d.stride, d.stuff = kks, 1, int(kstride == 2)
                 d.TH, d.TW, d.shape = 0, 0, -1
+                d.src = g   # (before the plan: data gradients get a block shape of their own)
                 capi.call("stl_conv_plan", C.byref(d))
-                d.src = g
                 d.w = self.wk.data_ptr() + ci.bwd_off * self.esz
                 dreads = [y.dt.data_ptr()]
                 if x.kind == "plain":

@@ -12,7 +12,7 @@ first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 count = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 nowg = len(sys.argv) > 4 and sys.argv[4] == "nowg"
 torch.manual_seed(0)
-m = PoseHighResolutionNet("w32", "bf16").cuda()
+m = PoseHighResolutionNet("w32", os.environ.get("STLPOSE_DTYPE", "mixed")).cuda()
 ts = TrainStep(m, 32, 384, 288)
 g = torch.Generator().manual_seed(1)
 ts.load_batch(torch.randn(32, 3, 384, 288, generator=g).cuda(), torch.rand(32, 17, 96, 72, generator=g).cuda(), torch.ones(32, 17, 1).cuda())
