@@ -252,16 +252,18 @@ int stl_bn_param_grads(const double* rstats, float* grads, const stl_bnrec* tab,
 
 /* Optimisers over the flat fp32 master (torch.optim.Adam / SGD semantics, reference
  * lib/model_setup.py:135-141).  hyper = device float[8]: lr, beta1, beta2, eps, weight_decay,
- * momentum, nesterov, gscale;  step = device int32 (incremented by the kernel).  An element whose gradient is
- * NaN or infinite is left untouched (weight and moments): see stl_bn_running_update. */
+ * momentum, nesterov, gscale;  step = device int32 (incremented by the kernel).  overflow: the word stl_bn_running_update
+ * maintains -- when it reports a non-finite forward tensor the WHOLE step is skipped (step is left negative, not counted:
+ * ReLU(NaN) = 0 can let the loss and the gradients of such a step come out finite and wrong); independently of it an element
+ * whose gradient is NaN or infinite is left untouched (weight and moments). */
 int stl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
-                  int32_t* step, void* stream);
+                  int32_t* step, const int32_t* overflow /* or NULL */, void* stream);
 int stl_sgd_step(float* p, const float* g, float* mom, int64_t n, const float* hyper, int32_t* step,
-                 void* stream);
+                 const int32_t* overflow /* or NULL */, void* stream);
 /* Per-bucket form: stl_optim_begin_step increments `step` once, the *_slice calls then update any
  * contiguous slices of the flat buffers (pointers already offset) with that step count -- the
  * optimiser of a gradient bucket runs as soon as the bucket is final, overlapped with backward. */
-int stl_optim_begin_step(int32_t* step, void* stream);
+int stl_optim_begin_step(int32_t* step, const int32_t* overflow /* or NULL */, void* stream);
 int stl_adam_slice(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
                    const int32_t* step, void* stream);
 int stl_sgd_slice(float* p, const float* g, float* mom, int64_t n, const float* hyper, const int32_t* step,

@@ -143,15 +143,15 @@ SIGNATURES = {
     "stl_final_preds": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "stl_weight_prep": [i32, vp, vp, vp, i32, i32, vp],
     "stl_weight_prep_range": [i32, vp, vp, vp, i32, i32, i32, vp],
-    "stl_optim_begin_step": [vp, vp],
+    "stl_optim_begin_step": [vp, vp, vp],
     "stl_adam_slice": [vp, vp, vp, vp, i64, vp, vp, vp],
     "stl_sgd_slice": [vp, vp, vp, i64, vp, vp, vp],
     "stl_reduce_slabs": [vp, vp, vp, i32, i32, vp],
     "stl_reduce_slabs_range": [C.POINTER(ReduceRange), vp],
     "stl_bn_running_update": [vp, vp, vp, vp, i32, f32, vp, vp],
     "stl_bn_param_grads": [vp, vp, vp, i32, vp],
-    "stl_adam_step": [vp, vp, vp, vp, i64, vp, vp, vp],
-    "stl_sgd_step": [vp, vp, vp, i64, vp, vp, vp],
+    "stl_adam_step": [vp, vp, vp, vp, i64, vp, vp, vp, vp],
+    "stl_sgd_step": [vp, vp, vp, i64, vp, vp, vp, vp],
     "stl_affine_crop": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp],
     "stl_maxpool2x2": [i32, vp, vp, i32, i32, i32, i32, vp],
     "stl_l1_partial": [i32, vp, vp, i64, vp, i32, vp],

@@ -172,21 +172,23 @@ __device__ __forceinline__ void mma16<float>(f32x4& acc, const V16& a, const V16
 // fp64 sqrt + divide it replaces costs ~60 in every kernel prologue).  The variance itself is still
 // formed in fp64 (sum of squares minus squared mean cancels).
 __device__ __forceinline__ float rsqrt_nr(float x) {
+#pragma clang fp contract(off)   // (the same roundings wherever it is inlined: see bn_affine)
     const float r = __frsqrt_rn(x);
-    return r * (1.5f - 0.5f * x * r * r);
+    const float h = 0.5f * x * r;
+    return r * fmaf(-h, r, 1.5f);
 }
 
 // a, b of y -> a * y + b for a BatchNorm given mean and 1 / std (the ReLU-mask BatchNorm of a data gradient's epilogue)
 __device__ __forceinline__ void bn_affine(float gamma, float beta, float mean, float rstd, float& a, float& b) {
 #pragma clang fp contract(off)   // (as below)
     a = gamma * rstd;
-    b = beta - mean * a;
+    b = fmaf(-mean, a, beta);   // one rounding, written out (what the contraction gave where it happened)
 }
 
 // ---------------------------------------------------------------- per-channel constants of an stl_src
 // ca/cb/cc: v = ca*x + cb (BN) or v = ca*dt + cb*y + cc (BNBWD).  mu/rs: mean and 1/std (for yhat).
 __device__ __forceinline__ void bn_mean_rstd(const stl_src& s, int c, int C, float& mean, float& rstd) {
-#pragma clang fp contract(off)   // per-channel constants: the same roundings in every kernel that derives them (no fused multiply-add here or there)
+#pragma clang fp contract(off)   // per-channel constants: the same roundings in every kernel that derives them (fused multiply-adds are written out)
     if (s.stats) {
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -195,7 +197,7 @@ __device__ __forceinline__ void bn_mean_rstd(const stl_src& s, int c, int C, flo
             s1 += s.stats[(size_t)k * 2 * C + C + c];
         }
         double m = s0 * (double)s.inv_count;
-        double var = s1 * (double)s.inv_count - m * m;
+        double var = fma(s1, (double)s.inv_count, -(m * m));
         if (var < 0.0) var = 0.0;
         mean = (float)m;
         rstd = rsqrt_nr((float)(var + (double)s.eps));
@@ -206,7 +208,7 @@ __device__ __forceinline__ void bn_mean_rstd(const stl_src& s, int c, int C, flo
 }
 
 __device__ __forceinline__ void src_consts(const stl_src& s, int c, int C, float& ca, float& cb, float& cc) {
-#pragma clang fp contract(off)   // per-channel constants: the same roundings in every kernel that derives them (no fused multiply-add here or there)
+#pragma clang fp contract(off)   // per-channel constants: the same roundings in every kernel that derives them (fused multiply-adds are written out)
     if (s.mode == STL_SRC_PLAIN) {
         ca = 1.f, cb = 0.f, cc = 0.f;
         return;
@@ -216,7 +218,7 @@ __device__ __forceinline__ void src_consts(const stl_src& s, int c, int C, float
     const float g = s.gamma[c];
     if (s.mode == STL_SRC_BN || s.mode == STL_SRC_BNADD) {
         ca = g * rstd;
-        cb = s.beta[c] - mean * ca;
+        cb = fmaf(-mean, ca, s.beta[c]);
         cc = 0.f;
     } else {  // BNBWD
         double r1 = 0.0, r2 = 0.0;
@@ -230,7 +232,7 @@ __device__ __forceinline__ void src_consts(const stl_src& s, int c, int C, float
         const float al = g * rstd;
         ca = al;
         cb = -al * rstd * c2;
-        cc = al * (mean * rstd * c2 - c1);
+        cc = al * fmaf(mean * rstd, c2, -c1);
     }
 }
 
@@ -256,13 +258,13 @@ __device__ __forceinline__ void bn_raw_load(const stl_src& s, int c, int C, SrcR
     }
 }
 __device__ __forceinline__ void bn_raw_finish(const stl_src& s, const SrcRaw& r, float& mean, float& rstd) {
-#pragma clang fp contract(off)   // per-channel constants: the same roundings in every kernel that derives them (no fused multiply-add here or there)
+#pragma clang fp contract(off)   // per-channel constants: the same roundings in every kernel that derives them (fused multiply-adds are written out)
     if (s.stats) {
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
         for (int k = 0; k < STL_NSHARD; ++k) s0 += r.st[2 * k], s1 += r.st[2 * k + 1];
         double m = s0 * (double)s.inv_count;
-        double var = s1 * (double)s.inv_count - m * m;
+        double var = fma(s1, (double)s.inv_count, -(m * m));
         if (var < 0.0) var = 0.0;
         mean = (float)m;
         rstd = rsqrt_nr((float)(var + (double)s.eps));
@@ -285,7 +287,7 @@ __device__ __forceinline__ void src_raw_load(const stl_src& s, int c, int C, Src
     }
 }
 __device__ __forceinline__ void src_raw_finish(const stl_src& s, const SrcRaw& r, float& ca, float& cb, float& cc) {
-#pragma clang fp contract(off)   // per-channel constants: the same roundings in every kernel that derives them (no fused multiply-add here or there)
+#pragma clang fp contract(off)   // per-channel constants: the same roundings in every kernel that derives them (fused multiply-adds are written out)
     if (s.mode == STL_SRC_PLAIN) {
         ca = 1.f, cb = 0.f, cc = 0.f;
         return;
@@ -294,7 +296,7 @@ __device__ __forceinline__ void src_raw_finish(const stl_src& s, const SrcRaw& r
     bn_raw_finish(s, r, mean, rstd);
     if (s.mode == STL_SRC_BN || s.mode == STL_SRC_BNADD) {
         ca = r.g * rstd;
-        cb = r.b - mean * ca;
+        cb = fmaf(-mean, ca, r.b);
         cc = 0.f;
     } else {
         double r1 = 0.0, r2 = 0.0;
@@ -305,7 +307,7 @@ __device__ __forceinline__ void src_raw_finish(const stl_src& s, const SrcRaw& r
         const float al = r.g * rstd;
         ca = al;
         cb = -al * rstd * c2;
-        cc = al * (mean * rstd * c2 - c1);
+        cc = al * fmaf(mean * rstd, c2, -c1);
     }
 }
 

@@ -863,7 +863,10 @@ Plan choose_plan(const stl_conv& p, int ck) {
     const int vrows = p.B * (p.Ho + 1);
     // kernel family (measured on MI355X): the wave-specialised kernel for stride-2 convolutions and for the
     // small, deep maps (Co >= 256 on <= 16384 pixels: their chains are the critical path of stage 4), the uniform kernel elsewhere
-    const bool deep_small = p.stride == 1 && p.ks == 3 && p.Co >= 256 && (int64_t)p.B * p.Ho * p.Wo <= 16384;
+    // (STL_CONV_R2 bit 3, default since round 5: these layers on the two-per-CU kernel's 128-pixel form instead -- 13.94 -> 13.83 ms per step)
+    const int r2_env = getenv("STL_CONV_R2") ? atoi(getenv("STL_CONV_R2")) : 11;
+    const bool deep_small = p.stride == 1 && p.ks == 3 && p.Co >= 256 && (int64_t)p.B * p.Ho * p.Wo <= 16384 &&
+                            !((r2_env & 8) && p.dtype != STL_F32 && p.Ci % 32 == 0 && p.Ci >= 64 && (r2_env & (p.src.mode == STL_SRC_BNBWD ? 2 : 1)));
     const bool want_ws = p.stride == 2 || deep_small;
     // 512 px x 32 co blocks: Co <= 32 with many input channels on a large map (8 chunks of K per tile)
     const bool wide_k = p.Co <= 32 && p.Ci >= 128 && p.stride == 1 && p.ks == 3 && !p.stuff && (int64_t)p.B * p.Ho * p.Wo >= 65536;
@@ -883,12 +886,14 @@ Plan choose_plan(const stl_conv& p, int ck) {
         if (shape == 2 || shape == 3 || shape == 5 || shape == 6) {
             static const bool db_on = !(getenv("STL_CONV_DB") && atoi(getenv("STL_CONV_DB")) == 0);
             // STL_CONV_R2 (A/B): bit 0 forward convolutions, bit 1 data gradients on the two-per-CU kernel (else the one-per-CU
-            // two-image block, shape 3); bit 2: forward convolutions on its 128-pixel form as well.  Default 3.
-            const int r2_mode = getenv("STL_CONV_R2") ? atoi(getenv("STL_CONV_R2")) : 3;   // (read per plan: plans are made once per layer)
+            // two-image block, shape 3); bit 2: forward convolutions on its 128-pixel form as well; bit 3: the deep small maps
+            // (Co >= 256 on <= 16384 pixels) on its 128-pixel form instead of the wave-specialised kernel.  Default 11.
+            const int r2_mode = r2_env;   // (read per plan: plans are made once per layer)
             const bool db = db_on && p.ks == 3 && p.stride == 1 && p.Ci > ck;
             const bool dgrad = p.src.mode == STL_SRC_BNBWD;   // (the planner sets the source before it asks for a plan)
             const bool r2 = db && (r2_mode & (dgrad ? 2 : 1)) && p.dtype != STL_F32 && p.Ci % 32 == 0 && p.Ci >= 64;
-            const int want = r2 ? ((dgrad || (r2_mode & 4)) ? 6 : 5) : (db ? 3 : 2);
+            const bool small_map = (r2_mode & 8) && p.Co >= 256 && (int64_t)p.B * p.Ho * p.Wo <= 16384;
+            const int want = r2 ? ((dgrad || (r2_mode & 4) || small_map) ? 6 : 5) : (db ? 3 : 2);
             if (shape != want) continue;
         }
         if ((shape == 1 || shape == 8) && p.Co > 32) continue;

@@ -730,12 +730,19 @@ __global__ __launch_bounds__(256) void bn_param_grads_kernel(const double* rstat
 }
 
 // ---------------------------------------------------------------- optimisers
-__global__ void inc_step_kernel(int32_t* step) { step[0] += 1; }
+// step counter of the fused optimisers.  A NEGATIVE value means "skip this step": the forward pass of the step stored a
+// non-finite forward tensor (stl_bn_running_update's overflow word; ReLU(NaN) = 0 lets the loss and the gradients come out
+// finite and wrong, so the gradient alone cannot tell) -- the weights must not move.  The skipped step is not counted.
+__global__ void inc_step_kernel(int32_t* step, const int32_t* overflow) {
+    const int t = step[0] < 0 ? -step[0] - 1 : step[0];   // steps taken so far (a skipped step is stored as -t - 1)
+    step[0] = (overflow && overflow[0] != 0x7fffffff) ? -t - 1 : t + 1;
+}
 
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n,
                                                    const float* hyper, const int32_t* step) {
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], gs = hyper[7];
     const int t = step[0];
+    if (t < 0) return;   // skipped step (inc_step_kernel)
     const float bc1 = 1.f - powf(b1, (float)t), bc2 = 1.f - powf(b2, (float)t);
     const float step_size = lr / bc1, isq2 = 1.f / sqrtf(bc2);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -753,6 +760,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
 __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, float* mom, int64_t n, const float* hyper,
                                                   const int32_t* step) {
     const float lr = hyper[0], wd = hyper[4], mu = hyper[5], nest = hyper[6], gs = hyper[7];
+    if (step[0] < 0) return;   // skipped step (inc_step_kernel)
     const bool first = step[0] <= 1;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float gi = g[i] * gs;
@@ -1205,22 +1213,23 @@ extern "C" int stl_bn_param_grads(const double* rstats, float* grads, const stl_
     return 0;
 }
 
-extern "C" int stl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, int32_t* step, void* stream) {
-    STL_LAUNCH(inc_step_kernel, dim3(1), dim3(1), 0, ST, step);
+extern "C" int stl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, int32_t* step, const int32_t* overflow,
+                             void* stream) {
+    STL_LAUNCH(inc_step_kernel, dim3(1), dim3(1), 0, ST, step, overflow);
     STL_LAUNCH(adam_kernel, dim3(nblocks_for((size_t)n, 256, 4096)), dim3(256), 0, ST, p, g, m, v, n, hyper, step);
     STL_LAUNCH_CHECK("adam_step");
     return 0;
 }
 
-extern "C" int stl_sgd_step(float* p, const float* g, float* mom, int64_t n, const float* hyper, int32_t* step, void* stream) {
-    STL_LAUNCH(inc_step_kernel, dim3(1), dim3(1), 0, ST, step);
+extern "C" int stl_sgd_step(float* p, const float* g, float* mom, int64_t n, const float* hyper, int32_t* step, const int32_t* overflow, void* stream) {
+    STL_LAUNCH(inc_step_kernel, dim3(1), dim3(1), 0, ST, step, overflow);
     STL_LAUNCH(sgd_kernel, dim3(nblocks_for((size_t)n, 256, 4096)), dim3(256), 0, ST, p, g, mom, n, hyper, step);
     STL_LAUNCH_CHECK("sgd_step");
     return 0;
 }
 
-extern "C" int stl_optim_begin_step(int32_t* step, void* stream) {
-    STL_LAUNCH(inc_step_kernel, dim3(1), dim3(1), 0, ST, step);
+extern "C" int stl_optim_begin_step(int32_t* step, const int32_t* overflow, void* stream) {
+    STL_LAUNCH(inc_step_kernel, dim3(1), dim3(1), 0, ST, step, overflow);
     STL_LAUNCH_CHECK("optim_begin_step");
     return 0;
 }

@@ -90,6 +90,14 @@ __device__ __forceinline__ WgBlock wg_block(const WgK& k) {
 }
 
 
+// Which pixel of a 32-pixel K step a lane's transposed read fetches (16-bit types): register i of lane (g = lane >> 4,
+// j = (lane & 15) >> 2) is MFMA k index 8 g + 4 i + j, and WHICH pixel sits at a k index is ours to choose as long as both
+// operands agree.  ds_read_b64_tr_b16 is served in two groups of 32 lanes (g = 0, 1 / g = 2, 3), eight rows of 32 bytes each:
+// with pixel = 8 g + 4 i + j (rounds 2-4) the rows are {4 i .. 4 i + 3} and {8 + 4 i ..}, eight apart, and rows eight apart
+// share a bank window at every pixel stride that is a multiple of 32 bytes (and strides that are not misalign the windows): every
+// fragment read took 4 LDS cycles instead of 2.  With pixel = 16 (g >> 1) + 8 i + 4 (g & 1) + j the eight rows are consecutive.
+__device__ __forceinline__ int krow16(int g, int i, int lane) { return 16 * (g >> 1) + 8 * i + 4 * (g & 1) + ((lane & 15) >> 2); }
+
 template <typename T>
 __device__ __forceinline__ V16 frag_tr(const char* base, const int* rowoff, int colbyte, int lane);
 // bf16: rows rowoff[0..1] are this lane's two 4-pixel groups (already including q); the read
@@ -152,20 +160,33 @@ __device__ __forceinline__ V16 frag_at<float>(const uint32_t* addr, int off) {
 // t + 2 are issued while tile t is multiplied, so a tile's memory round trip (~2 us when 256 blocks load at once)
 // is covered by two iterations instead of being exposed once per tile (it was ~80 % of the K loop).
 // TY: element type of the FORWARD tensors (h.x, g.y); T: the gradient dt = g.x and the MFMA operands
-template <typename T, int KS, int NVH, bool GQ, int TPX, int OCC, int NW, typename TY = T>
+// CH: channels per block in each direction (round 5).  32: the block's 32 x 32 channels are four 16 x 16 quadrants, NW / 4 tap
+// groups.  64 (NW = 16, 1024 threads, bf16, 3x3): 64 x 64 channels = sixteen quadrants, one per wave, all nine taps (36
+// accumulator registers): ONE staged pixel tile feeds four times the MFMAs -- with 32-channel blocks a C = 64 layer stages every
+// pixel four times (once per chunk pair), a C = 128 layer sixteen times, and the staging (loads, BatchNorm-backward transform,
+// LDS writes, barriers), not the matrix pipe, is what a tile costs.  The per-thread shape is the 32-channel kernel's (one g and
+// two h staging vectors, twice the threads for twice the channels in each tensor); 128 registers for 16 waves means ONE register
+// set of staged loads (NSET = 1: the next tile is requested behind the barrier and lands during the 36 MFMAs per wave).
+// NSET: register sets of staged loads (2: tile t + 2 in flight while tile t is multiplied).
+template <typename T, int KS, int NVH, bool GQ, int TPX, int OCC, int NW, typename TY = T, int CH = 32, int NSET = 2>
 __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KV = ET<T>::KV, TAPS = KS * KS;
     constexpr int KSTEP = 4 * KV;               // pixels per MFMA K step (32 bf16 / 16 f32)
     constexpr int NR = sizeof(T) == 2 ? 2 : 4;  // row offsets a lane needs per fragment
-    constexpr int VPX = 32 / KV;                // 16-byte vectors per pixel (32 channels)
+    constexpr int VPX = CH / KV;                // 16-byte vectors per pixel (CH channels)
     constexpr int NT = 64 * NW;                 // threads per block
     constexpr int NVG = TPX * VPX / NT;         // g staging vectors per thread
     static_assert(NVG >= 1 && NVG * NT == TPX * VPX, "g staging slots must tile the block");
-    constexpr int NTG = NW / 4;                 // tap groups (NW = 8: waves 0-3 take taps 0..4, waves 4-7 taps 5..8)
+    constexpr int QW = CH / 16, WPG = QW * QW;  // 16 x 16 quadrants per side / waves per tap group (one quadrant each)
+    static_assert((CH == 32 || CH == 64) && NW % WPG == 0 && (NSET == 1 || NSET == 2), "channel tile / wave count");
+    constexpr int NTG = NW / WPG;               // tap groups (CH = 32, NW = 8: waves 0-3 take taps 0..4, waves 4-7 taps 5..8)
     constexpr int TPG = (TAPS + NTG - 1) / NTG; // taps per group (accumulators per wave)
-    constexpr int PS = 32 * (int)sizeof(T) + 16;  // LDS bytes per pixel (== k.psg == k.psh): compile-time, so that tap and
-                                                  // K-step offsets of the fragment reads are instruction immediates
+    // LDS bytes per pixel (== k.psg == k.psh): compile-time, so that tap and K-step offsets of the fragment reads are
+    // instruction immediates.  16-bit types: 32 bytes of padding, an ODD multiple of 32 in total -- with the K order of
+    // krow() below the eight pixel rows one transposed read touches per 32 lanes are CONSECUTIVE pixels, and
+    // consecutive rows of 96 (160) bytes fall into the eight disjoint 32-byte bank windows: conflict-free.
+    constexpr int PS = CH * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
     constexpr int NKT = TPX / KSTEP;            // K steps per tile
     const stl_wgrad& p = k.p;
     // grouped launch: blockIdx.x = member * nsplit + split.  The member's tensors come from k.io[member] (a uniform,
@@ -175,11 +196,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
     const int member = wb.member, bsplit = wb.bsplit;
     const stl_wgrad_io& io = k.io[member];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-    const int mt = (wave & 3) >> 1, nt = wave & 1, tg = wave >> 2;
-    const int co0 = wb.cy * 32, ci0 = wb.cz * 32;
+    const int mt = (wave % WPG) / QW, nt = wave % QW, tg = wave / WPG;
+    const int co0 = wb.cy * CH, ci0 = wb.cz * CH;
     WSTAMP(0);
-    float* cgc = reinterpret_cast<float*>(smem + k.off_cg);  // [3][32]
-    float* chc = reinterpret_cast<float*>(smem + k.off_ch);  // [2][32]
+    float* cgc = reinterpret_cast<float*>(smem + k.off_cg);  // [3][CH]
+    float* chc = reinterpret_cast<float*>(smem + k.off_ch);  // [2][CH]
     char* sG = smem + k.off_g;
     char* sH = smem + k.off_h;
 
@@ -217,7 +238,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
     uint32_t gaw[NR], hbw[NKT][NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-        const int c = sizeof(T) == 2 ? 8 * g + 4 * i + ((lane & 15) >> 2) : 4 * g + i;
+        const int c = sizeof(T) == 2 ? krow16(g, i, lane) : 4 * g + i;
         gaw[i] = (uint32_t)(uintptr_t)sG + c * PS + lterm + mt * 16 * (int)sizeof(T);
 #pragma unroll
         for (int s = 0; s < NKT; ++s) {
@@ -228,9 +249,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
         }
     }
 
-    // ---- two register sets of staged loads
-    V16 rgv[2][NVG], rgq[2][GQ ? NVG : 1], rhv[2][NVH];
-    uint32_t okm[2] = {0u, 0u};   // validity bits of a set: bit i = g slot i, bit NVG + i = h slot i
+    // ---- register sets of staged loads
+    V16 rgv[NSET][NVG], rgq[NSET][GQ ? NVG : 1], rhv[NSET][NVH];
+    uint32_t okm[NSET] = {};   // validity bits of a set: bit i = g slot i, bit NVG + i = h slot i
 
     // unconditional loads (a guarded load would be serialised by the compiler); invalid slots read element 0 and
     // are zeroed when written to LDS
@@ -250,8 +271,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
         h_lo[i] = (uint32_t)(((h_rc[i] >> 16) * p.Wi + (h_rc[i] & 0xffff)) * h_cbytes + (ci0 + g_part * KV) * (int)sizeof(T));
         if (h_rc[i] >= 0 && h_chok) slot_ok |= 1u << (NVG + i);
     }
-    auto fetch = [&](auto SET, int t) __attribute__((always_inline)) {
-        constexpr int S = decltype(SET)::value;
+    // byte offsets of tile t's staging slots (0 for slots outside the tensors) and their validity bits
+    auto tile_offsets = [&](int t, uint32_t* go, uint32_t* ho) __attribute__((always_inline)) -> uint32_t {
         const int tr = sdiv(t, k.m_tc), tc = t - tr * k.tiles_c;
         const int vr0 = tr * p.TH, c0 = tc * p.TW;
         const int gb0 = sdiv(vr0, k.m_vp), gy0 = vr0 - gb0 * vpitch;
@@ -263,10 +284,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
             const int wr_ = fdiv(oy0 < 0 ? 0 : oy0, k.r_vp);
             const int oy = mad24_vsv(wr_, n_vp, oy0);
             const bool in = ((slot_ok >> i) & 1u) & (gb0 + wr_ < p.B) & (oy < p.Ho) & (c < p.Wo);
-            const uint32_t off = in ? (uint32_t)mad24_vsv(wr_, g_wrap, (int)(g_t + g_lo[i])) : 0u;
+            go[i] = in ? (uint32_t)mad24_vsv(wr_, g_wrap, (int)(g_t + g_lo[i])) : 0u;
             ok |= in ? 1u << i : 0u;
-            rgv[S][i] = ldg16((const char*)io.g.x + off);
-            if (GQ) rgq[S][i] = ldg16((const char*)io.g.y + off);
         }
         const int vrs = vr0 * p.stride, cb = c0 * p.stride - k.pad;
         const int hb0 = sdiv(vrs, k.m_PI), hy0 = vrs - hb0 * k.PI - k.pad;
@@ -277,11 +296,26 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
             const int wr_ = fdiv(iy0 < 0 ? 0 : iy0, k.r_PI);
             const int iy = mad24_vsv(wr_, n_PI, iy0);
             const bool in = ((slot_ok >> (NVG + i)) & 1u) & (iy0 >= 0) & (ix >= 0) & (ix < p.Wi) & (hb0 + wr_ < p.B) & (iy < p.Hi);
-            const uint32_t off = in ? (uint32_t)mad24_vsv(wr_, h_wrap, (int)(h_t + h_lo[i])) : 0u;
+            ho[i] = in ? (uint32_t)mad24_vsv(wr_, h_wrap, (int)(h_t + h_lo[i])) : 0u;
             ok |= in ? 1u << (NVG + i) : 0u;
-            rhv[S][i] = ldg16((const char*)io.h.x + off);
         }
+        return ok;
+    };
+    auto load_set = [&](auto SET, const uint32_t* go, const uint32_t* ho, uint32_t ok) __attribute__((always_inline)) {
+        constexpr int S = decltype(SET)::value;
+#pragma unroll
+        for (int i = 0; i < NVG; ++i) {
+            rgv[S][i] = ldg16((const char*)io.g.x + go[i]);
+            if (GQ) rgq[S][i] = ldg16((const char*)io.g.y + go[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NVH; ++i) rhv[S][i] = ldg16((const char*)io.h.x + ho[i]);
         okm[S] = ok;
+    };
+    auto fetch = [&](auto SET, int t) __attribute__((always_inline)) {
+        uint32_t go[NVG], ho[NVH];
+        const uint32_t ok = tile_offsets(t, go, ho);
+        load_set(SET, go, ho, ok);
     };
     const float relu_lo = io.h.relu ? 0.f : -INFINITY;
     auto write_lds = [&](auto SET) __attribute__((always_inline)) {
@@ -290,7 +324,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
 #pragma unroll
         for (int i = 0; i < NVG; ++i) {
             V16 val = rgv[S][i];
-            if (GQ) val = xform_bnbwd<T, TY>(val, rgq[S][i], cgc + cl, cgc + 32 + cl, cgc + 64 + cl);
+            if (GQ) val = xform_bnbwd<T, TY>(val, rgq[S][i], cgc + cl, cgc + CH + cl, cgc + 2 * CH + cl);
             mask16(val, (okm[S] >> i) & 1u);
             const int v = tid + i * NT;
             *reinterpret_cast<V16*>(sG + (v / VPX) * PS + g_part * 16) = val;
@@ -301,7 +335,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
             // as a whole leaves its load pending on that path, and the wait-count pass then drains EVERY outstanding
             // load (the other set's too) in front of the next instruction that overwrites the register
             V16 val = rhv[S][i];
-            if (io.h.mode == STL_SRC_BN) val = xform_bn<T, TY>(val, chc + cl, chc + 32 + cl, relu_lo);
+            if (io.h.mode == STL_SRC_BN) val = xform_bn<T, TY>(val, chc + cl, chc + CH + cl, relu_lo);
             else val = xform_cvt<T, TY>(val);
             mask16(val, (okm[S] >> (NVG + i)) & 1u);
             const int v = tid + i * NT;
@@ -318,7 +352,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
     // LLVM folds the tap / K-step offsets into the instructions instead of hoisting one address register per read.
     auto mfma_taps = [&](auto TAP0, auto NTAP) __attribute__((always_inline)) {
         constexpr int T0 = decltype(TAP0)::value, NTP = decltype(NTAP)::value;   // this wave's taps [T0, T0 + NTP)
-        constexpr int NJ = NKT * NTP, PF = NTP >= 4 ? 6 : 2;
+        constexpr int NJ = NKT * NTP, PF = NTP >= 4 ? (CH == 64 ? 4 : 6) : 2;
         uint32_t ga[NR], hb[NKT][NR];
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
@@ -361,11 +395,12 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
     const int step = p.nsplit;
     int t = bsplit;
     WSTAMP(1);
-    // BatchNorm constants (wave 3: lanes 0-31 those of g, 32-63 those of h): the statistics loads are issued ahead
-    // of the first tiles' loads, the arithmetic runs while those are in flight
+    // BatchNorm constants (the last 2 CH threads of waves 0-3: CH channels of g, then CH of h; CH = 32: wave 3): the statistics
+    // loads are issued ahead of the first tiles' loads, the arithmetic runs while those are in flight
     SrcRaw raw;
-    const bool cw = wave == 3, cg = lane < 32;
-    const int cch = lane & 31;
+    const int cidx = tid - (256 - 2 * CH);
+    const bool cw = cidx >= 0 && cidx < 2 * CH, cg = cidx < CH;
+    const int cch = cidx & (CH - 1);
     const bool cok = cw && (cg ? co0 + cch < p.Co : ci0 + cch < p.Ci);
     if (cok) {
         if (cg) src_raw_load(io.g, co0 + cch, p.Co, raw);
@@ -374,7 +409,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
     constexpr std::integral_constant<int, 0> I0{};
     constexpr std::integral_constant<int, 1> I1{};
     if (t < k.npt) fetch(I0, t);
-    if (t + step < k.npt) fetch(I1, t + step);
+    if constexpr (NSET == 2) {
+        if (t + step < k.npt) fetch(I1, t + step);
+    }
     WSTAMP(2);
     if (cw) {
         float a = 0.f, b = 0.f, cc = 0.f;
@@ -382,8 +419,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
             if (cg) src_raw_finish(io.g, raw, a, b, cc);
             else src_raw_finish(io.h, raw, a, b, cc);
         }
-        if (cg) cgc[cch] = a, cgc[32 + cch] = b, cgc[64 + cch] = cc;
-        else chc[cch] = a, chc[32 + cch] = b;
+        if (cg) cgc[cch] = a, cgc[CH + cch] = b, cgc[2 * CH + cch] = cc;
+        else chc[cch] = a, chc[CH + cch] = b;
     }
     __syncthreads();  // constants visible
     WSTAMP(3);
@@ -395,7 +432,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
         __syncthreads();
         WSTAMP2(4 * dbg_i + 1);
         if (first) WSTAMP(4);
-        if (t + 2 * step < k.npt) fetch(SET, t + 2 * step);   // block-uniform: two tiles ahead, into the set just drained
+        // (A register-free L2 prefetch of tile t + 2 -- 4-byte LDS-DMA touches of every staging slot -- made the 16-wave block
+        // SLOWER, 67.7 -> 73.6 us per eight-layer launch: its tile is bound by vector-instruction issue, not by the round trip.)
+        if (t + NSET * step < k.npt) fetch(SET, t + NSET * step);   // block-uniform: NSET tiles ahead, into the set just drained
         WSTAMP2(4 * dbg_i + 2);
         mfma_tile();
         __syncthreads();
@@ -415,8 +454,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
     // need the staging loads and their waits written as inline assembly.
     while (t < k.npt) {
         body(I0);
-        if (t >= k.npt) break;
-        body(I1);
+        if constexpr (NSET == 2) {
+            if (t >= k.npt) break;
+            body(I1);
+        }
     }
     WSTAMP(6);
     {   // every wave writes its quadrant (and its taps) of the block's slab [Co][taps][Ci]
@@ -436,18 +477,19 @@ __global__ __launch_bounds__(64 * NW, OCC) void wgrad_kernel(const WgK k) {
 }
 
 
-template <typename T, typename TY, int KS, int NVH, bool GQ, int TPX = 128, int NW = 4>
+template <typename T, typename TY, int KS, int NVH, bool GQ, int TPX = 128, int NW = 4, int CH = 32>
 int launch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
-    constexpr int OCC = (NVH * NW <= 24 && TPX == 128 && sizeof(T) == 2) ? 2 : 1;
+    constexpr int OCC = NW == 16 ? 4 : ((NVH * NW <= 24 && TPX == 128 && sizeof(T) == 2) ? 2 : 1);
+    constexpr int NSET = CH == 64 ? 1 : 2;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, KS, NVH, GQ, TPX, OCC, NW, TY>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, KS, NVH, GQ, TPX, OCC, NW, TY, CH, NSET>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    STL_LAUNCH((wgrad_kernel<T, KS, NVH, GQ, TPX, OCC, NW, TY>), grid, dim3(64 * NW), lds, st, k);
+    STL_LAUNCH((wgrad_kernel<T, KS, NVH, GQ, TPX, OCC, NW, TY, CH, NSET>), grid, dim3(64 * NW), lds, st, k);
     static char nbuf[160];
-    static const char* nm = stl_kname<T>(nbuf, "wgrad_kernel", {KS, NVH, GQ, TPX, OCC, NW, stl_code<TY>()});
+    static const char* nm = stl_kname<T>(nbuf, "wgrad_kernel", {KS, NVH, GQ, TPX, OCC, NW, stl_code<TY>(), CH});
     stl_note_kernel(nm, true);
     STL_LAUNCH_CHECK("conv_wgrad");
     return 0;
@@ -515,12 +557,12 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(const WgK k) {
     // ---- MFMA-side offsets: pixel m = 32 s + 8 g + 4 i + ((lane & 15) >> 2) of K step s
     int rg0[NR], rh[NKS][NR];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) rg0[i] = (8 * g + 4 * i + ((lane & 15) >> 2)) * k.psg;
+    for (int i = 0; i < NR; ++i) rg0[i] = krow16(g, i, lane) * k.psg;
 #pragma unroll
     for (int s = 0; s < NKS; ++s)
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            int m = s * KSTEP + 8 * g + 4 * i + ((lane & 15) >> 2);
+            int m = s * KSTEP + krow16(g, i, lane);
             if (m >= tilepx) m = 0;  // the G rows beyond the tile are zero
             const int ty = fdiv(m, k.r_TW), tx = m - ty * p.TW;
             rh[s][i] = ((ty * p.stride) * k.HC + tx * p.stride) * k.psh;
@@ -723,7 +765,15 @@ dim3 wg_grid(WgK& k, int units, int gy, int gz) {
 }
 
 // channel tile (64 or 32) of the kernel variant stl_conv_wgrad picks for this problem
+// 3x3 stride-1 layers with at least 64 channels on both sides (bf16): 64 x 64 channels per 16-wave block of wgrad_kernel
+// (round 5; STL_WGRAD_C64=0: the 32-channel blocks -- A/B)
+static bool wgrad_c64_3x3(const stl_wgrad& p) {
+    const char* e = getenv("STL_WGRAD_C64");
+    return !(e && atoi(e) == 0) && p.dtype == STL_BF16 && p.ks == 3 && p.stride == 1 && p.Co >= 64 && p.Ci >= 64;
+}
+
 int wgrad_chunk(const stl_wgrad& p) {
+    if (wgrad_c64_3x3(p)) return 64;
     // The wide variant serves the 1x1 convolutions only: there it halves the re-reads of the 113 MB layer1 tensors and its
     // slabs are small (21.8 vs 22.0 ms per step in round 1; without it 15.48 vs 14.5 in round 3).  For 3x3 layers it loses as
     // much again to the 4x larger split-K slabs and to its 256 VGPRs (15.33 -> 16.42-17.24 ms per step): removed in round 4.
@@ -744,6 +794,14 @@ int dispatch(const WgK& k, dim3 grid, size_t lds, hipStream_t st) {
     const int nvh = ceil_div(k.HP * vpx, 256);
     const bool gq = k.p.g.mode == STL_SRC_BNBWD;
     STL_CHECK(k.p.TH * k.p.TW <= 128, "wgrad: tiles of more than 128 pixels are not supported");
+    if constexpr (KS == 3 && sizeof(T) == 2) {
+        if (k.p.ks == 3 && wgrad_c64_3x3(k.p)) {   // 64 x 64 channels per 16-wave block
+            const int nvh16 = ceil_div(k.HP * 8, 1024);
+            if (nvh16 <= 2) return gq ? launch<T, TY, KS, 2, true, 128, 16, 64>(k, grid, lds, st) : launch<T, TY, KS, 2, false, 128, 16, 64>(k, grid, lds, st);
+            if (nvh16 <= 3) return gq ? launch<T, TY, KS, 3, true, 128, 16, 64>(k, grid, lds, st) : launch<T, TY, KS, 3, false, 128, 16, 64>(k, grid, lds, st);
+            return stl_set_error("wgrad: halo of %d pixels is too large for the 64-channel 3x3 kernel; shrink the tile", k.HP);
+        }
+    }
     if constexpr (KS == 3) {   // 8 waves: quadrants x two tap groups, half the staging work per thread (bf16 and fp32)
         const int nvh8 = ceil_div(k.HP * vpx, 512);
         if (nvh8 <= 2) return gq ? launch<T, TY, KS, 2, true, 128, 8>(k, grid, lds, st) : launch<T, TY, KS, 2, false, 128, 8>(k, grid, lds, st);
@@ -854,6 +912,16 @@ static int wgrad_run(const stl_wgrad* const* ps, int ng, void* stream) {
     k.m_tc = (two32 + k.tiles_c - 1) / k.tiles_c, k.m_vp = (two32 + p.Ho) / (p.Ho + 1), k.m_PI = (two32 + k.PI - 1) / k.PI;
     STL_CHECK((int64_t)k.npt < (1 << 21) && (int64_t)p.B * k.PI < (1 << 21), "wgrad: too many tiles");
     hipStream_t st = (hipStream_t)stream;
+    if (wgrad_c64_3x3(p)) {   // wgrad_kernel with 64-channel blocks: pixel stride 144 B, constants [3][64] + [2][64]
+        k.psg = k.psh = 64 * 2 + 32;
+        k.off_cg = 0, k.off_ch = 3 * 64 * 4, k.off_g = 2048;
+        k.off_h = k.off_g + 128 * k.psg;
+        const size_t ldsw = (size_t)k.off_h + (size_t)k.HP * k.psh;
+        STL_CHECK(ldsw <= 160 * 1024, "wgrad: tile needs %zu B of LDS (>160 KiB)", ldsw);
+        STL_CHECK(p.nsplit <= k.npt || p.nsplit == 1, "wgrad: nsplit %d > tiles %d", p.nsplit, k.npt);
+        dim3 gridw = wg_grid(k, p.nsplit * ng, ceil_div(p.Co, 64), ceil_div(p.Ci, 64));
+        return stl_wgrad_backend_bf16(false, k, gridw, ldsw, st);
+    }
     if (wgrad_chunk(p) == 64) {
         k.psg = k.psh = 160;
         k.off_cg = 0, k.off_ch = 3 * 64 * 4, k.off_g = 2048;  // consts: g [3][64] at 0, h [2][64] at 768
@@ -865,7 +933,7 @@ static int wgrad_run(const stl_wgrad* const* ps, int ng, void* stream) {
         return stl_wgrad_backend_bf16(true, k, grid64, lds64, st);
     }
     const int esz = p.dtype == STL_BF16 ? 2 : 4;
-    k.psg = k.psh = 32 * esz + 16;
+    k.psg = k.psh = 32 * esz + (esz == 2 ? 32 : 16);
     k.off_cg = 0;
     k.off_ch = 3 * 32 * 4;
     k.off_g = 1024;  // consts: g [3][32] floats at 0, h [2][32] floats at 384 -> 640 B used

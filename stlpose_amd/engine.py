@@ -182,6 +182,9 @@ class Engine:
         self.wgrad_blocks = int(env("STLPOSE_WGRAD_BLOCKS", "512"))
         # members per grouped launch (round 3 at 256 blocks: 1 / 2 / 4 / 8 = 15.87 / 15.64 / 16.03 / 17.51; 4 at 512 blocks: 15.36)
         self.wgrad_group = int(env("STLPOSE_WGRAD_GROUP", "4"))
+        # the 64-channel 3x3 blocks (16 waves, one per CU: 256 per launch): eight layers per launch keep the split-K slabs at the
+        # 32-channel kernel's size (a slab is the whole [Co][9][Ci] filter bank; 256 blocks over four layers would double them)
+        self.wgrad_group_wide = int(env("STLPOSE_WGRAD_GROUP_WIDE", "8"))
         self.skip_wgrad = env("STLPOSE_SKIP_WGRAD", "0") != "0"   # calibration only (wrong numerics): no weight-gradient launches
         # STLPOSE_GRAPH=1: replay each program as ONE explicit HIP graph (csrc/program.hip: kernel nodes + the planner's
         # dependencies) instead of launches and events on four streams
@@ -660,17 +663,19 @@ class Engine:
         wg.dtype, wg.ydtype = self.dtype, self.ydtype
         wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = x.B, x.H, x.W, x.C, y.H, y.W, y.C
         wg.ks, wg.stride = kks, kstride
-        ctile = capi.lib().stl_wgrad_chunk(C.byref(wg))   # 32, or 64 for the wide-channel variant (1x1 layers)
-        wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32, maxhalo=192 if ctile == 64 else 576)
+        ctile = capi.lib().stl_wgrad_chunk(C.byref(wg))   # 32, or 64: the 1x1 layers' wide kernel and the 16-wave 3x3 blocks (C >= 64)
+        wide3 = ctile == 64 and kks == 3   # 64 x 64 channels per 1024-thread block: ONE block per CU, up to eight layers per launch
+        wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32, maxhalo=(256 if wide3 else 192) if ctile == 64 else 576)   # (256 halo pixels: two staging vectors per thread of the 16-wave block)
         npt = math.ceil(x.B * (y.H + 1) / wg.TH) * math.ceil(y.W / wg.TW)
         chunks = math.ceil(y.C / ctile) * math.ceil(x.C / ctile)
-        budget = self.wgrad_blocks
+        budget = self.wgrad_blocks // 2 if wide3 else self.wgrad_blocks
         # The single-branch tail of backward (layer1, stem, transition1) is one serial data-gradient chain beside three idle
         # queues: a group there fills only when the chain has walked through ALL its members (every layer1 group completes
         # at the first block, i.e. at the very end of the step), so grouped weight gradients pile up behind the chain:
         # tail launches are not grouped (round 3, groups of 4 / 2 / 1: 15.02 / 14.81 / 14.82 ms per step).
         tail = self._active_of(ci.key) == 1
-        gsize = 1 if (tail or self.skip_wgrad) else max(1, min(self.wgrad_group, capi.WGRAD_GROUP_MAX, max(1, budget // chunks)))
+        gmax = self.wgrad_group_wide if wide3 else self.wgrad_group
+        gsize = 1 if (tail or self.skip_wgrad) else max(1, min(gmax, capi.WGRAD_GROUP_MAX, max(1, budget // chunks)))
         # Grouped launches (stl_conv_wgrad_group): weight gradients of one shape -- the 3x3 convolutions of a branch --
         # wait until `gsize` of them are ready and go out as ONE launch that shares the block budget: the four hardware
         # queues carry one off-chain launch instead of gsize (in stages 3 / 4 every queue is busy with a data-gradient
@@ -864,7 +869,8 @@ class Engine:
         raise FloatingPointError(
             f"stlpose_amd: the raw output of the convolution in front of {name[:-len('.weight')] if name.endswith('.weight') else name} "
             f"left the range of its {what} storage (non-finite BatchNorm statistics; first such layer in forward order).  "
-            "The optimiser skipped that step, the weights and running statistics are intact.  Forward tensors of the default "
+            "The optimiser skipped that step (and skips every step until this is reported): the weights are intact; the running "
+            "statistics of the layers behind it took their momentum update from the poisoned pass.  Forward tensors of the default "
             "'mixed' mode are f16; for a checkpoint with badly scaled weights use compute_dtype='bf16' (same speed, bf16 range) "
             "or 'fp32'.")
 

@@ -143,7 +143,7 @@ class TrainStep:
         if self._loss_scale != 1.0 or self._loss_offset != 0.0:   # the kernel scales only dL/dout
             self.loss.mul_(self._loss_scale).add_(self._loss_offset)
         if fused_optim:
-            capi.call("stl_optim_begin_step", self.step_count.data_ptr(), st)
+            capi.call("stl_optim_begin_step", self.step_count.data_ptr(), self.eng.overflow.data_ptr(), st)
         # per-bucket issue while backward is being enqueued: RCCL only ("nccl": the collective is a kernel enqueued on the
         # communicator's stream, the host does not wait); gloo's all-reduce of a device tensor makes the host wait for the stream
         dp_on = self.dp is not None and (self.world > 1 or self._force_dp) and not self.use_graph and self._dp_rccl
@@ -157,10 +157,10 @@ class TrainStep:
         s = self.store
         if self.kind == ADAM:
             capi.call("stl_adam_step", s.master.data_ptr(), s.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                      s.nparam, self.hyper.data_ptr(), self.step_count.data_ptr(), st)
+                      s.nparam, self.hyper.data_ptr(), self.step_count.data_ptr(), self.eng.overflow.data_ptr(), st)
         else:
             capi.call("stl_sgd_step", s.master.data_ptr(), s.grads.data_ptr(), self.m.data_ptr(), s.nparam,
-                      self.hyper.data_ptr(), self.step_count.data_ptr(), st)
+                      self.hyper.data_ptr(), self.step_count.data_ptr(), self.eng.overflow.data_ptr(), st)
 
     def _issue_bucket(self, i: int):
         """Enqueue gradient bucket i's all-reduce on the communication stream, behind the bucket's event.  Called by

@@ -177,6 +177,7 @@ class Trainer:
         st, ts = self.ts.store, self.ts
         names = [k for k, _ in st.reg.params]
         step = int(ts.step_count.item())
+        step = step if step >= 0 else -step - 1   # (negative: the last step was skipped, see TrainStep.check_forward_range)
         state = {}
         for i, (k, shape) in enumerate(st.reg.params):
             a = st.param_off[k]

@@ -90,26 +90,31 @@ def test_planner_dry_run(monkeypatch):
     assert b["stl_conv_forward"] == 291 and b["stl_upsample_backward"] == 28
     assert len(e.slabs) == 292 + 2   # + head weight and bias
     e0, c0 = e, b
-    assert nwg == 292 and 0 < c0["stl_conv_wgrad_group"] < 80 and c0["stl_conv_wgrad"] < 80   # most layers ride in groups of up to 4
+    assert nwg == 292 and 0 < c0["stl_conv_wgrad_group"] < 80 and c0["stl_conv_wgrad"] < 80   # most layers ride in groups
     for o in e0.bwd_ops:
         if o[0] == "stl_conv_wgrad_group":
             ms = o[1].members
-            assert 2 <= o[1].n <= 4 and len({(m.Ci, m.Co, m.ks, m.stride, m.Hi, m.Wi, m.TH, m.TW, m.nsplit, m.g.mode) for m in ms}) == 1
+            # up to 4 per launch on the 32-channel blocks, up to 8 on the 64-channel 3x3 blocks (C >= 64; round 5)
+            assert 2 <= o[1].n <= (8 if ms[0].Ci >= 64 and ms[0].Co >= 64 and ms[0].ks == 3 else 4)
+            assert len({(m.Ci, m.Co, m.ks, m.stride, m.Hi, m.Wi, m.TH, m.TW, m.nsplit, m.g.mode) for m in ms}) == 1
     monkeypatch.setenv("STLPOSE_WGRAD_GROUP", "1")
+    monkeypatch.setenv("STLPOSE_WGRAD_GROUP_WIDE", "1")
     assert Counter(o[0] for o in Engine(m.arch, m._store, 2, 256, 192, capi.BF16, True).bwd_ops)["stl_conv_wgrad"] == 292
     monkeypatch.delenv("STLPOSE_WGRAD_GROUP")
+    monkeypatch.delenv("STLPOSE_WGRAD_GROUP_WIDE")
     assert len(e.bns) == 292 and e.out.shape == (2, 17, 64, 48)
     ev = Engine(m.arch, m._store, 1, 64, 64, capi.F32, False)
     assert not ev.bwd_ops
     # residual block ends formed by the consuming conv1 (STL_SRC_BNADD): at the benchmarked size the 3 inner block ends of every
-    # branch with a block-end kernel variant are eligible (24 + 24 + 21 = 69: C = 32, 64, 128); the default merges C >= 128 only
+    # branch with a block-end kernel variant are eligible (24 + 24 + 21 + 9 = 78: C = 32, 64, 128 and, since the deep small
+    # maps run on the two-per-CU kernel -- round 5 --, C = 256); the default merges C >= 128 only
     def merged(e):
         return Counter(o[1].Ci for o in e.fwd_ops if o[0] == "stl_conv_forward" and o[1].src.mode == capi.SRC_BNADD)
     eb = Engine(m.arch, m._store, 32, 384, 288, capi.BF16, True)
-    assert merged(eb) == {128: 21} and Counter(o[0] for o in eb.fwd_ops)["stl_fuse_forward"] == 136 - 21
+    assert merged(eb) == {128: 21, 256: 9} and Counter(o[0] for o in eb.fwd_ops)["stl_fuse_forward"] == 136 - 30
     monkeypatch.setenv("STLPOSE_MERGE_MINC", "0")
     ea = Engine(m.arch, m._store, 32, 384, 288, capi.BF16, True)
-    assert merged(ea) == {32: 24, 64: 24, 128: 21} and Counter(o[0] for o in ea.fwd_ops)["stl_fuse_forward"] == 136 - 69
+    assert merged(ea) == {32: 24, 64: 24, 128: 21, 256: 9} and Counter(o[0] for o in ea.fwd_ops)["stl_fuse_forward"] == 136 - 78
     for o in ea.fwd_ops:   # the merged conv writes the sum it consumed: src_out is the tensor the fuse launch would have produced
         if o[0] == "stl_conv_forward" and o[1].src.mode == capi.SRC_BNADD:
             assert o[1].src_out and o[1].src.y and o[1].src_out in o[4]

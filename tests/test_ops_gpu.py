@@ -170,8 +170,8 @@ def test_conv_bn_relu_chain_forward_backward(case, dt):
     wg.dtype, wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = code, B, H, W, Ci, Ho, Wo, Co
     wg.ks, wg.stride, wg.ydtype = ks, s, ydt
     ctile = capi.lib().stl_wgrad_chunk(C.byref(wg))   # 64: wide-channel kernel variant (bf16 1x1 layers with Co, Ci >= 64)
-    assert ctile == (64 if (dt in ("bf16", "mixed") and ks == 1 and Ci >= 64 and Co >= 64) else 32)
-    wg.TH, wg.TW = choose_tile(B, Ho, Wo, s, ks, x0t.element_size(), bn_cols=32, maxhalo=192 if ctile == 64 else 576)
+    assert ctile == (64 if (dt in ("bf16", "mixed") and s == 1 and Ci >= 64 and Co >= 64) else 32)
+    wg.TH, wg.TW = choose_tile(B, Ho, Wo, s, ks, x0t.element_size(), bn_cols=32, maxhalo=((256 if ks == 3 else 192) if ctile == 64 else 576))
     npt = math.ceil(B * (Ho + 1) / wg.TH) * math.ceil(Wo / wg.TW)
     wg.nsplit = min(3, npt)
     part = torch.full((wg.nsplit * Co * ks * ks * Ci,), float("nan"), device="cuda")
@@ -618,9 +618,9 @@ def test_optimizers_match_torch():
             pt.grad = gr.clone()
             opt.step()
             if kind == "adam":
-                capi.call("stl_adam_step", pk.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), n, hyper.data_ptr(), step.data_ptr(), stream())
+                capi.call("stl_adam_step", pk.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), n, hyper.data_ptr(), step.data_ptr(), None, stream())
             else:
-                capi.call("stl_sgd_step", pk.data_ptr(), gr.data_ptr(), m.data_ptr(), n, hyper.data_ptr(), step.data_ptr(), stream())
+                capi.call("stl_sgd_step", pk.data_ptr(), gr.data_ptr(), m.data_ptr(), n, hyper.data_ptr(), step.data_ptr(), None, stream())
         torch.cuda.synchronize()
         assert int(step.item()) == 3
         assert torch.allclose(pk, pt.detach(), rtol=1e-5, atol=1e-6), kind
@@ -788,6 +788,51 @@ def test_gaussian_targets_match_reference_golden(golden_dir):
         assert np.array_equal(tw.cpu().numpy(), g[f"{tag}_tw"])
         assert np.abs(tgt.cpu().numpy() - g[f"{tag}_target"]).max() < 2e-7
         assert np.array_equal(tgt.cpu().numpy() > 0, g[f"{tag}_target"] > 0)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "mixed"])
+@pytest.mark.parametrize("case", [(4, 48, 36, 64, 64, 5), (3, 24, 18, 128, 128, 2), (2, 24, 18, 96, 72, 3), (2, 12, 9, 256, 256, 1), (2, 13, 11, 64, 192, 4)])
+def test_wgrad_64_channel_blocks_equal_32_channel_blocks(case, dt, monkeypatch):
+    """The 3x3 weight gradient on 64 x 64-channel blocks of 16 waves (round 5: every pixel tile staged once per 64 channels, one
+    quadrant and all nine taps per wave) against the 32 x 32-channel blocks on the same tensors, tile and split: each slab
+    element is the same sum over the same pixels in the same order (K runs over the tile's pixels inside one wave either way),
+    so the slabs are BIT-identical.  Ragged channel counts (96, 72) exercise the half-empty blocks."""
+    code, td, tol = DT[dt]
+    fcode, ftd = FDT[dt]
+    ydt = fcode if fcode != code else 0
+    B, H, W, Ci, Co, ns = case
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x0t = nhwc(torch.randn(B, Ci, H, W, device="cuda", generator=g) * 1.5 + 0.3, ftd)
+    yk = nhwc(torch.randn(B, Co, H, W, device="cuda", generator=g), ftd)
+    dtt = nhwc(torch.randn(B, Co, H, W, device="cuda", generator=g), td)
+    g1, b1 = torch.rand(Ci, device="cuda", generator=g) + 0.5, torch.rand(Ci, device="cuda", generator=g) - 0.5
+    g2 = torch.rand(Co, device="cuda", generator=g) + 0.5
+    st1, st2 = stats_of(x0t, Ci), stats_of(yk, Co)
+    ykf, dtf = yk.view(-1, Co).double(), dtt.view(-1, Co).double()
+    mean2, rstd2 = ykf.mean(0), 1.0 / torch.sqrt(ykf.var(0, unbiased=False) + EPS)
+    rst2 = torch.zeros(capi.NSHARD, 2, Co, dtype=torch.float64, device="cuda")
+    rst2[0, 0], rst2[0, 1] = dtf.sum(0), (dtf * (ykf - mean2) * rstd2).sum(0)
+    gs = capi.Src()
+    gs.x, gs.y, gs.mode = dtt.data_ptr(), yk.data_ptr(), capi.SRC_BNBWD
+    gs.stats, gs.rstats, gs.gamma = st2.data_ptr(), rst2.data_ptr(), g2.data_ptr()
+    gs.inv_count, gs.eps = 1.0 / (B * H * W), EPS
+
+    def run(c64):
+        monkeypatch.setenv("STL_WGRAD_C64", c64)
+        wg = capi.Wgrad()
+        wg.dtype, wg.B, wg.Hi, wg.Wi, wg.Ci, wg.Ho, wg.Wo, wg.Co = code, B, H, W, Ci, H, W, Co
+        wg.ks, wg.stride, wg.ydtype = 3, 1, ydt
+        assert capi.lib().stl_wgrad_chunk(C.byref(wg)) == (64 if c64 == "1" else 32)
+        wg.TH, wg.TW = choose_tile(B, H, W, 1, 3, 2, bn_cols=32, maxhalo=256)
+        wg.nsplit = min(ns, math.ceil(B * (H + 1) / wg.TH) * math.ceil(W / wg.TW))
+        part = torch.full((wg.nsplit * Co * 9 * Ci,), float("nan"), device="cuda")
+        wg.h, wg.g, wg.partial = bn_src(x0t, st1, g1, b1, B * H * W, True), gs, part.data_ptr()
+        capi.call("stl_conv_wgrad", C.byref(wg), stream())
+        torch.cuda.synchronize()
+        assert ("64>" in capi.lib().stl_last_kernel().decode()) == (c64 == "1"), capi.lib().stl_last_kernel().decode()
+        return part
+    a, b = run("1"), run("0")
+    assert not torch.isnan(a).any() and torch.equal(a, b)
 
 
 @pytest.mark.parametrize("ws", ["xcd-grid", "plain-grid"])

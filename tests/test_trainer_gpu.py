@@ -210,7 +210,7 @@ def test_f16_overflow_of_a_badly_scaled_checkpoint_is_reported_not_trained_on():
     """Forward tensors of the default mixed mode are f16 (|y| <= 65504); lib/model_setup.py:38-42 loads arbitrary checkpoints.
     A checkpoint whose convolution weights are 1e5 x too large (BatchNorm hides the scale from an fp32 run) overflows the raw
     conv outputs: the step must not train on it silently -- the BatchNorm statistics carry the infinity, the running
-    statistics and the weights stay as they were (the optimiser skips non-finite gradients) and the host gets a
+    statistics and the weights stay as they were (the optimiser skips the step) and the host gets a
     FloatingPointError that names the layer and the remedy.  The same checkpoint trains in the bf16 mode."""
     from stlpose_amd import PoseHighResolutionNet
     from stlpose_amd.train_step import TrainStep
@@ -231,7 +231,7 @@ def test_f16_overflow_of_a_badly_scaled_checkpoint_is_reported_not_trained_on():
         return m, ts, w0, rm0, float(loss.item())
 
     m, ts, w0, rm0, loss = run("mixed")
-    assert not np.isfinite(loss)
+    # (the loss itself may even be FINITE: ReLU(NaN) = 0 wipes the poisoned maps -- which is why the guard rides on the statistics)
     with pytest.raises(FloatingPointError, match="compute_dtype='bf16'") as ei:
         ts.check_forward_range()
     assert "conv" in str(ei.value) or "layer" in str(ei.value) or "bn" in str(ei.value), str(ei.value)
