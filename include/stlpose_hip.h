@@ -43,8 +43,9 @@ extern "C" {
 #define STL_SRC_BNBWD 2 /* v = a*(dt - r1/n - yhat*r2/n): BatchNorm backward on load */
 #define STL_SRC_BNADD 3 /* v = [relu](a*x + b + y): a residual block end z = ReLU(BN(x) + y) (HRnet.py:58-59) formed while the
                            NEXT unit's first convolution stages its input; x = raw conv output, y = the skip tensor (same
-                           shape, PLAIN).  stl_conv_forward only (3x3 stride 1); with stl_conv.src_out the sum is also
-                           written out once, for the skip connection and the backward pass */
+                           shape, PLAIN).  stl_conv_forward only (3x3 stride 1, and 1x1 with Ci, Co >= 64: layer1's
+                           bottleneck units, HRnet.py:88-100); with stl_conv.src_out the sum is also written out once, for the
+                           skip connection and the backward pass */
 
 typedef struct stl_src {
     const void* x;        /* PLAIN/BN: tensor; BNBWD: dt (grad wrt BN output, post ReLU mask) */

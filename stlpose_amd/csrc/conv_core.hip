@@ -974,7 +974,8 @@ extern "C" int stl_conv_plan(stl_conv* pp) {
 
 extern "C" int stl_conv_bnadd_ok(const stl_conv* pp) {
     const stl_conv& p = *pp;
-    if (!(p.ks == 3 && p.stride == 1 && !p.stuff && p.shape >= 0 && p.shape < NSHAPES && p.TH > 0 && p.TW > 0) || use_1x1(p)) return 0;
+    if (use_1x1(p)) return 1;   // the streaming 1x1 kernel's block-end form (conv1x1.inc, ZM)
+    if (!(p.ks == 3 && p.stride == 1 && !p.stuff && p.shape >= 0 && p.shape < NSHAPES && p.TH > 0 && p.TW > 0)) return 0;
     const Shape sh = SHAPES[p.shape];
     const int nva = ceil_div((p.TH + 2) * (p.TW + 2) * 4, sh.lthr);
     return bnadd_shape_ok(p.shape, nva) ? 1 : 0;
@@ -1004,8 +1005,8 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     STL_CHECK(p.src.x && p.w && p.out, "conv: null tensor pointer");
     STL_CHECK(p.src.mode >= 0 && p.src.mode <= 3, "conv: bad src mode");
     const bool zm = p.src.mode == STL_SRC_BNADD;
-    STL_CHECK(!zm || (p.ks == 3 && p.stride == 1 && !p.stuff && p.src.y && p.src.beta && (p.src.stats || (p.src.rmean && p.src.rvar))),
-              "conv: a BNADD source needs a 3x3 stride-1 convolution, the skip tensor in src.y and BatchNorm parameters");
+    STL_CHECK(!zm || (((p.ks == 3 && p.stride == 1 && !p.stuff) || use_1x1(p)) && p.src.y && p.src.beta && (p.src.stats || (p.src.rmean && p.src.rvar))),
+              "conv: a BNADD source needs a 3x3 stride-1 (or wide 1x1) convolution, the skip tensor in src.y and BatchNorm parameters");
     STL_CHECK(zm || !p.src_out, "conv: src_out needs a BNADD source");
     STL_CHECK(!zm || (!p.bias && !p.addend && !p.mask_y && !p.mask_z && !p.red), "conv: a BNADD source takes no epilogue operands");
     STL_CHECK(p.src.mode == STL_SRC_PLAIN || p.src.gamma, "conv: BN source without gamma");

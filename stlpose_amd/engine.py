@@ -294,11 +294,11 @@ class Engine:
         capi.call("stl_conv_plan", C.byref(p))  # block shape + pixel tile, searched once
         reads, writes = [x.ptr], [y.ptr]
         pend = x.pending
-        if (pend is not None and kks == 3 and kstride == 1 and pend[0][2] == self._stream and self.merge_minc <= x.C
+        if (pend is not None and kstride == 1 and kks in (1, 3) and pend[0][2] == self._stream and self.merge_minc <= x.C
                 and capi.lib().stl_conv_bnadd_ok(C.byref(p)) == 1):
-            # Residual block end z = ReLU(BN(y2) + skip) whose FIRST consumer is this 3x3 convolution (the next unit's
-            # conv1): the sum is formed while the conv stages its tiles and written out once from the tile interiors
-            # (STL_SRC_BNADD + src_out) -- the stand-alone sum launch and one pass over the tensor go (HRnet.py:58-59).
+            # Residual block end z = ReLU(BN(y2) + skip) whose FIRST consumer is this convolution (the next unit's conv1: 3x3
+            # in the branches, 1x1 in layer1 -- round 5): the sum is formed while the conv stages its tiles and written out once
+            # (STL_SRC_BNADD + src_out) -- the stand-alone sum launch and one pass over the tensor go (HRnet.py:58-59, 88-100).
             fop, ybn, skip = pend
             self.fwd_ops.remove(fop)
             p.src = self._src(ybn, relu=True)

@@ -107,14 +107,16 @@ def test_planner_dry_run(monkeypatch):
     assert not ev.bwd_ops
     # residual block ends formed by the consuming conv1 (STL_SRC_BNADD): at the benchmarked size the 3 inner block ends of every
     # branch with a block-end kernel variant are eligible (24 + 24 + 21 + 9 = 78: C = 32, 64, 128 and, since the deep small
-    # maps run on the two-per-CU kernel -- round 5 --, C = 256); the default merges C >= 128 only
+    # maps run on the two-per-CU kernel -- round 5 --, C = 256), plus the two layer1 sums whose first consumer is a 1x1
+    # bottleneck convolution (256 -> 64; round 5); the default merges C >= 128 only
     def merged(e):
         return Counter(o[1].Ci for o in e.fwd_ops if o[0] == "stl_conv_forward" and o[1].src.mode == capi.SRC_BNADD)
     eb = Engine(m.arch, m._store, 32, 384, 288, capi.BF16, True)
-    assert merged(eb) == {128: 21, 256: 9} and Counter(o[0] for o in eb.fwd_ops)["stl_fuse_forward"] == 136 - 30
+    assert merged(eb) == {128: 21, 256: 11} and Counter(o[0] for o in eb.fwd_ops)["stl_fuse_forward"] == 136 - 32
+    assert sum(1 for o in eb.fwd_ops if o[0] == "stl_conv_forward" and o[1].src.mode == capi.SRC_BNADD and o[1].ks == 1) == 2
     monkeypatch.setenv("STLPOSE_MERGE_MINC", "0")
     ea = Engine(m.arch, m._store, 32, 384, 288, capi.BF16, True)
-    assert merged(ea) == {32: 24, 64: 24, 128: 21, 256: 9} and Counter(o[0] for o in ea.fwd_ops)["stl_fuse_forward"] == 136 - 78
+    assert merged(ea) == {32: 24, 64: 24, 128: 21, 256: 11} and Counter(o[0] for o in ea.fwd_ops)["stl_fuse_forward"] == 136 - 80
     for o in ea.fwd_ops:   # the merged conv writes the sum it consumed: src_out is the tensor the fuse launch would have produced
         if o[0] == "stl_conv_forward" and o[1].src.mode == capi.SRC_BNADD:
             assert o[1].src_out and o[1].src.y and o[1].src_out in o[4]

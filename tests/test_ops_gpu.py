@@ -898,27 +898,29 @@ def test_wgrad_group_equals_single_launches(case, dt, ws, monkeypatch):
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16", "f16"])
-@pytest.mark.parametrize("case", [(4, 48, 36, 32, 32), (4, 24, 18, 64, 64), (3, 24, 18, 128, 128), (2, 12, 16, 16, 16), (2, 10, 4, 48, 48), (2, 13, 7, 32, 64)])
+@pytest.mark.parametrize("case", [(4, 48, 36, 32, 32), (4, 24, 18, 64, 64), (3, 24, 18, 128, 128), (2, 12, 16, 16, 16), (2, 10, 4, 48, 48), (2, 13, 7, 32, 64),
+                                  (2, 24, 18, 256, 64, 1), (3, 13, 11, 128, 192, 1), (2, 12, 9, 256, 256)])
 def test_conv_block_end_source_bnadd(case, dt):
-    """STL_SRC_BNADD: z = ReLU(BN(y) + skip) formed while the 3x3 conv stages its input, and written out once
-    (src_out) -- against torch: conv2d(relu(batch_norm(y) + skip)) and the sum itself; and bit-identical to the
-    two-launch form (stl_fuse_forward, then the conv on the plain sum)."""
-    B, H, W, Ci, Co = case
+    """STL_SRC_BNADD: z = ReLU(BN(y) + skip) formed while the conv stages its input (3x3, or the streaming 1x1 kernel: layer1's
+    bottleneck units, round 5), and written out once (src_out) -- against torch: conv2d(relu(batch_norm(y) + skip)) and the sum
+    itself; and bit-identical to the two-launch form (stl_fuse_forward, then the conv on the plain sum)."""
+    B, H, W, Ci, Co = case[:5]
+    ks = case[5] if len(case) > 5 else 3
     code, td, tol = DT[dt]
     torch.manual_seed(11)
     y = torch.randn(B, Ci, H, W, device="cuda") * 1.5 + 0.3
     skip = torch.relu(torch.randn(B, Ci, H, W, device="cuda"))
     g, b = torch.rand(Ci, device="cuda") + 0.5, torch.randn(Ci, device="cuda") * 0.2
-    w = torch.randn(Co, Ci, 3, 3, device="cuda") * (2.0 / (Ci * 9)) ** 0.5
+    w = torch.randn(Co, Ci, ks, ks, device="cuda") * (2.0 / (Ci * ks * ks)) ** 0.5
     yt, st_, wt = nhwc(y, td), nhwc(skip, td), w.permute(0, 2, 3, 1).contiguous().to(td)     # [Co][tap][Ci]
     stats = stats_of(yt, Ci)
     zr = torch.relu(F.batch_norm(from_nhwc(yt, B, H, W, Ci), None, None, g, b, True, 0.0, EPS) + from_nhwc(st_, B, H, W, Ci))
-    ref = F.conv2d(from_nhwc(nhwc(zr, td), B, H, W, Ci), wt.float().permute(0, 3, 1, 2), padding=1)
+    ref = F.conv2d(from_nhwc(nhwc(zr, td), B, H, W, Ci), wt.float().permute(0, 3, 1, 2), padding=ks // 2)
     out = torch.full((B * H * W * Co,), float("nan"), device="cuda", dtype=td)
     z = torch.full((B * H * W * Ci,), float("nan"), device="cuda", dtype=td)
     p = capi.Conv()
     p.shape = -1
-    p.dtype, p.B, p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.Co, p.ks, p.stride = code, B, H, W, Ci, H, W, Co, 3, 1
+    p.dtype, p.B, p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.Co, p.ks, p.stride = code, B, H, W, Ci, H, W, Co, ks, 1
     capi.call("stl_conv_plan", C.byref(p))
     if capi.lib().stl_conv_bnadd_ok(C.byref(p)) != 1:
         pytest.skip(f"block shape {p.shape} has no block-end variant (the planner keeps the separate sum launch there)")
@@ -942,7 +944,7 @@ def test_conv_block_end_source_bnadd(case, dt):
     capi.call("stl_fuse_forward", C.byref(f), stream())
     q = capi.Conv()
     q.shape = -1
-    q.dtype, q.B, q.Hi, q.Wi, q.Ci, q.Ho, q.Wo, q.Co, q.ks, q.stride = code, B, H, W, Ci, H, W, Co, 3, 1
+    q.dtype, q.B, q.Hi, q.Wi, q.Ci, q.Ho, q.Wo, q.Co, q.ks, q.stride = code, B, H, W, Ci, H, W, Co, ks, 1
     q.TH, q.TW, q.shape = p.TH, p.TW, p.shape
     q.src.x, q.src.mode = z2.data_ptr(), capi.SRC_PLAIN
     out2 = torch.empty_like(out)
