@@ -683,6 +683,7 @@ int launch(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
 //   3 = 256 x 64, 8 waves, two LDS images, one barrier per stage -- the C >= 64 3x3 layers (forward and data gradient; round 4)
 //   5 = 256 x 64, 8 waves, <= 128 VGPRs and <= 76 KB of LDS: TWO PER CU (conv_r2.inc, round 5: filters by LDS-DMA, planar halo image) --
 //       the C >= 64 3x3 stride-1 forward convolutions of the 16-bit modes; launches it has no instantiation for fall back to shape 3
+//  10 = 256 x 32, 8 waves along the pixels, the same kernel for the C <= 32 layers (STL_CONV_R2 bit 4; fallback: shape 8)
 //   6 = 128 x 64, 8 waves, the same kernel with two pixel tiles per wave -- their data gradients (a second source tensor and up
 //       to three epilogue operands beside 32 accumulators do not fit 128 registers; with 16 they do); fallback: shape 0
 //   4 = 128 x 32, 4 waves  -- C <= 32 fallback where no 256-pixel tile fits (<= 128 VGPRs, <= 40 KB LDS: four blocks per CU)
@@ -695,11 +696,11 @@ struct Shape {
     int ws;            // 1: wave-specialised kernel (4 loader + 4 compute waves, double-buffered LDS); 2: uniform kernel, two LDS images; 3: conv_r2
     int lthr, nva_max; // threads that stage the halo, max staging vectors per such thread
 };
-constexpr int NSHAPES = 10;
+constexpr int NSHAPES = 11;
 constexpr Shape SHAPES[NSHAPES] = {{128, 64, 256, 0, 256, 9}, {512, 32, 512, 0, 512, 6}, {256, 64, 512, 0, 512, 3},
                                    {256, 64, 512, 2, 512, 3}, {128, 32, 256, 0, 256, 6},
                                    {256, 64, 512, 3, 512, 3}, {128, 64, 512, 3, 512, 2}, {128, 64, 512, 1, 256, 9},
-                                   {256, 32, 512, 0, 512, 3}, {128, 32, 512, 1, 256, 3}};
+                                   {256, 32, 512, 0, 512, 3}, {128, 32, 512, 1, 256, 3}, {256, 32, 512, 3, 512, 3}};
 
 // EO >= 0 (data gradients whose operand set the planner emits in bulk): own instantiations of the C >= 64 3x3 block (the
 // C <= 32 block at its 128-register budget spills 6 - 12 registers once the compiler may interleave the tiles)
@@ -747,7 +748,7 @@ int dispatch(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStrea
 // block-end source (STL_SRC_BNADD): the shapes the two-conv units of the network are planned with -- 256 px x 32 co
 // (C <= 32), 256 px x 64 co (C = 64 / 128) and their small-map fallbacks; own instantiations, so that the
 // data-gradient kernels (Q without ZM) carry none of this
-static bool bnadd_shape_ok(int shape, int nva) { return nva <= 3 && (shape == 0 || shape == 2 || shape == 3 || shape == 4 || shape == 5 || shape == 6 || shape == 8); }
+static bool bnadd_shape_ok(int shape, int nva) { return nva <= 3 && (shape == 0 || shape == 2 || shape == 3 || shape == 4 || shape == 5 || shape == 6 || shape == 8 || shape == 10); }
 template <typename T>
 int dispatch_bnadd(int shape, int nva, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     if (nva <= 3) switch (shape) {
@@ -772,7 +773,7 @@ int conv_backend(int path, const stl_conv& p, const ConvK& k, int shape, int nva
     constexpr bool FWD = std::is_same<T, TY>::value, BWD = !std::is_same<T, f16>::value;
     if (path == 0) return run_1x1<T, TY>(p, st);
     if (path == 3) {
-        if constexpr (sizeof(T) == 2) return dispatch_r2<T, TY>(p, k, shape == 5 ? 4 : 2, grid, lds, st);
+        if constexpr (sizeof(T) == 2) return dispatch_r2<T, TY>(p, k, shape == 5 ? 0 : (shape == 6 ? 1 : 2), grid, lds, st);
         return stl_set_error("conv_r2: 16-bit element types only");
     }
     if (path == 1) {
@@ -826,7 +827,7 @@ size_t lds_bytes(const stl_conv& p, int shape, int TH, int TW, int ck, ConvK* ou
         const int off_b = (off + 1023) & ~1023;   // 1-KB DMA pieces
         off = off_b + bco * R2_ROWF;
         const int off_red = off;
-        off += 4 * 2 * bco * 4;
+        off += 512 * 4;   // [WM][2][BCO] floats: 4 x 2 x 64 = 8 x 2 x 32
         if (out) {
             out->HR = HR, out->HC = HC, out->HP = HR * HC, out->nchunks = nchunks, out->cipad = cipad;
             out->off_cs = 0, out->off_cm = off_cm, out->off_a = off_a, out->off_b = off_b, out->off_red = off_red;
@@ -896,9 +897,13 @@ Plan choose_plan(const stl_conv& p, int ck) {
             const int want = r2 ? ((dgrad || (r2_mode & 4) || small_map) ? 6 : 5) : (db ? 3 : 2);
             if (shape != want) continue;
         }
-        if ((shape == 1 || shape == 8) && p.Co > 32) continue;
-        if ((shape == 4 || shape == 8) && !c32) continue;
-        if (c32 && shape != 4 && shape != 8) continue;
+        if ((shape == 1 || shape == 8 || shape == 10) && p.Co > 32) continue;
+        if ((shape == 4 || shape == 8 || shape == 10) && !c32) continue;
+        if (c32 && shape != 4 && shape != 8 && shape != 10) continue;
+        {   // C <= 32 on the two-per-CU kernel's 256 x 32 form (STL_CONV_R2 bit 4) instead of conv_core_kernel's shape 8
+            const bool r2c32 = (r2_env & 16) && p.dtype != STL_F32 && p.Ci == 32 && (r2_env & (p.src.mode == STL_SRC_BNBWD ? 2 : 1));
+            if (c32 && (shape == 8 || shape == 10) && (shape == 10) != r2c32) continue;
+        }
         if (wide_k && shape != 1) continue;
         const int nblk_co = ceil_div(p.Co, sh.co);
         for (int tw = (p.Wo < 4 ? p.Wo : 4); tw <= p.Wo && tw <= sh.px; ++tw)
@@ -912,7 +917,7 @@ Plan choose_plan(const stl_conv& p, int ck) {
             const size_t lds = lds_bytes(p, shape, th, tw, ck, nullptr);
             if (shape == 4 && lds > 40 * 1024 && nva <= 3) continue;  // keep four blocks per CU
             if (shape == 8 && lds > 80 * 1024) continue;              // ... resp. two 8-wave blocks
-            if ((shape == 5 || shape == 6) && lds > 76 * 1024) continue;   // two per CU in mixed company
+            if ((shape == 5 || shape == 6 || shape == 10) && lds > 76 * 1024) continue;   // two per CU in mixed company
             if (lds > 158 * 1024) continue;
             const double tiles = (double)ceil_div(vrows, th) * ceil_div(p.Wo, tw);
             // cost model (arbitrary units): MFMA work of all launched tiles (padding included), the
@@ -924,7 +929,7 @@ Plan choose_plan(const stl_conv& p, int ck) {
             const double waves = blocks * sh.thr / 64.0;
             if (waves < 2048.0) cost *= 1.0 + 0.15 * (2048.0 / waves - 1.0 > 4.0 ? 4.0 : 2048.0 / waves - 1.0);
             if (c32 && shape == 4) cost *= 4.0;   // fallback only
-            if (shape == 5 || shape == 6) cost *= 0.98;   // wins ties against the four-wave 128 x 64 block (small problems: both at the wave-count penalty's cap)
+            if (shape == 5 || shape == 6 || shape == 10) cost *= 0.98;   // wins ties against the four-wave 128 x 64 block (small problems: both at the wave-count penalty's cap)
             if (cost < best.cost) best = Plan{shape, th, tw, lds, cost};
         }
     }
@@ -1034,8 +1039,9 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
         STL_CHECK(plan.shape >= 0, "conv: no tile fits LDS for %dx%d ks %d stride %d Ci %d", p.Ho, p.Wo, p.ks, p.stride, p.Ci);
     }
     // an operand set / source conv_r2 has no instantiation for: conv_core_kernel's block of the same pixel count, same tile
-    if (plan.shape == 5 && !r2_takes(p, 4)) plan.shape = 3;
-    if (plan.shape == 6 && !r2_takes(p, 2)) plan.shape = 0;
+    if (plan.shape == 5 && !r2_takes(p, 0)) plan.shape = 3;
+    if (plan.shape == 6 && !r2_takes(p, 1)) plan.shape = 0;
+    if (plan.shape == 10 && !r2_takes(p, 2)) plan.shape = 8;
     {
         const Shape shp = SHAPES[plan.shape];
         const int nv = ceil_div(((plan.TH - 1) * p.stride + p.ks) * ((plan.TW - 1) * p.stride + p.ks) * 4, shp.lthr);
@@ -1077,6 +1083,7 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     if (plan.shape == 8) cap = 384;
     if (plan.shape == 5) cap = 512;   // two per CU
     if (plan.shape == 6) cap = 768;   // three per CU (<= 55 KB of LDS, <= 128 VGPRs)
+    if (plan.shape == 10) cap = getenv("STL_R2_CAP10") ? atoi(getenv("STL_R2_CAP10")) : 768;   // <= 45 KB of LDS: three per CU
     cap = std::max(8, (cap / k.ny + 7) / 8 * 8);
     if (const char* e = getenv("STL_CONV_GRID_CAP")) cap = atoi(e) > 0 ? (atoi(e) + 7) / 8 * 8 : cap;   // tools/conv_probe.py
     if (gx > cap) gx = cap;
@@ -1086,6 +1093,6 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
         fprintf(stderr, "[stl conv] %dx%d Ci%d Co%d ks%d s%d: shape=%d tile=%dx%d npt=%d grid=(%d x %d) lds=%zu nva=%d nchunks=%d\n", p.Ho,
                 p.Wo, p.Ci, p.Co, p.ks, p.stride, plan.shape, plan.TH, plan.TW, k.npt, gx, k.ny, lds, nva, k.nchunks);
     hipStream_t st = (hipStream_t)stream;
-    return backend((plan.shape == 5 || plan.shape == 6) ? 3 : (zm ? 1 : 2), p, k, plan.shape, nva, grid, lds, st);
+    return backend((plan.shape == 5 || plan.shape == 6 || plan.shape == 10) ? 3 : (zm ? 1 : 2), p, k, plan.shape, nva, grid, lds, st);
 }
 #endif   // STL_HAS_BF16

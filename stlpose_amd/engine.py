@@ -176,7 +176,7 @@ class Engine:
         # 15.50 vs 15.33-15.43 ms per step; C <= 32 / C <= 64 / C >= 64 / C >= 128 only: 15.53 / 15.51 / 15.45 / 15.36): the conv
         # re-forms the sum for every halo pixel and every output-channel block, which costs what the saved launch bought.
         self.merge_minc = int(env("STLPOSE_MERGE_MINC", "128"))
-        self.bucket_mb = float(env("STLPOSE_BUCKET_MB", "32"))    # gradient bucket size (16 -> 32 MB: 16.79 -> 16.66 ms per step)
+        self.bucket_mb = float(env("STLPOSE_BUCKET_MB", "64"))    # gradient bucket size (16 -> 32 MB: 16.79 -> 16.66 ms per step in round 2; 32 -> 64: 13.50 -> 13.42 in round 5)
         # block budget of a weight-gradient launch (a group shares it): 512 = two 8-wave blocks per CU, which hide each other's
         # tile latency (round 3, grouped launches: 128 / 256 / 512 / 768 blocks = 17.65 / 16.03 / 15.36 / 15.57 ms per step)
         self.wgrad_blocks = int(env("STLPOSE_WGRAD_BLOCKS", "512"))

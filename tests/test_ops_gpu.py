@@ -290,7 +290,7 @@ def test_conv_two_image_block_equals_single_image(case, dt, monkeypatch):
 @pytest.mark.parametrize("cap", ["16", ""])
 @pytest.mark.parametrize("dt", ["bf16", "mixed"])
 @pytest.mark.parametrize("case", [(4, 48, 36, 64, 64), (3, 24, 18, 128, 128), (2, 24, 18, 96, 64), (2, 24, 18, 64, 192), (2, 96, 72, 64, 64), (3, 13, 11, 256, 128),
-                                  (2, 20, 14, 128, 224)])
+                                  (2, 20, 14, 128, 224), (4, 96, 72, 32, 32), (3, 48, 36, 32, 32), (2, 21, 13, 32, 16)])
 def test_conv_two_per_cu_kernel_equals_one_per_cu_block(case, dt, cap, monkeypatch):
     """conv_r2_kernel (round 5: <= 128 VGPRs, <= 76 KB of LDS, filters by LDS-DMA into an unpadded swizzled image, planar halo
     image; block shapes 5 = 256 px and 6 = 128 px) against conv_core_kernel's one-per-CU block (shape 3) on the same launch:
@@ -301,6 +301,8 @@ def test_conv_two_per_cu_kernel_equals_one_per_cu_block(case, dt, cap, monkeypat
     fcode, ftd = FDT[dt]
     ydt = fcode if fcode != code else 0
     B, H, W, Ci, Co = case
+    c32 = Ci == 32 and Co <= 32          # the C <= 32 layers: shape 8 (or its small-map fallback 4) -> the 256 x 32 form, shape 10
+    NEW = "31" if c32 else "3"           # STL_CONV_R2: forward + data gradients (+ deep small maps + C <= 32)
     if cap:
         monkeypatch.setenv("STL_CONV_GRID_CAP", cap)
     g = torch.Generator(device="cuda").manual_seed(15)
@@ -325,18 +327,19 @@ def test_conv_two_per_cu_kernel_equals_one_per_cu_block(case, dt, cap, monkeypat
             p.src.mode, p.src.y, p.src_out = capi.SRC_BNADD, skip.data_ptr(), zk.data_ptr()
         p.w, p.out, p.out_stats = wt.data_ptr(), yk.data_ptr(), st2.data_ptr()
         capi.call("stl_conv_plan", C.byref(p))
-        assert p.shape == want, f"planner chose block shape {p.shape}, expected {want}"
+        assert p.shape in want, f"planner chose block shape {p.shape}, expected one of {want}"
         capi.call("stl_conv_forward", C.byref(p), stream())
         torch.cuda.synchronize()
-        assert capi.lib().stl_last_kernel().decode().startswith("conv_r2_kernel") == (want in (5, 6))
+        assert capi.lib().stl_last_kernel().decode().startswith("conv_r2_kernel") == (p.shape in (5, 6, 10))
         return yk, st2, zk, p
-    y3, s3, _, p3 = forward("0", 3)
-    for r2, want in (("3", 5), ("7", 6)):
+    OLD = (8, 4) if c32 else (3,)
+    y3, s3, _, p3 = forward("0", OLD)
+    for r2, want in (((NEW, (10,)),) if c32 else (("3", (5,)), ("7", (6,)))):
         y5, s5, _, _ = forward(r2, want)
         assert not torch.isnan(y5.float()).any() and torch.equal(y5, y3), (r2, want)
         assert torch.allclose(tot(s5), tot(s3), rtol=1e-6, atol=1e-4)
-    yb3, sb3, zb3, _ = forward("0", 3, bnadd=True)
-    for r2, want in (("3", 5), ("7", 6)):
+    yb3, sb3, zb3, _ = forward("0", OLD, bnadd=True)
+    for r2, want in (((NEW, (10,)),) if c32 else (("3", (5,)), ("7", (6,)))):
         yb, sb, zb, _ = forward(r2, want, bnadd=True)
         assert not torch.isnan(yb.float()).any() and torch.equal(yb, yb3) and torch.equal(zb, zb3), (r2, want)
         assert torch.allclose(tot(sb), tot(sb3), rtol=1e-6, atol=1e-4)
@@ -369,19 +372,23 @@ def test_conv_two_per_cu_kernel_equals_one_per_cu_block(case, dt, cap, monkeypat
         if "mz" in ops:
             d.mask_z = zmask.data_ptr()
         capi.call("stl_conv_plan", C.byref(d))
-        if want == 3 and d.shape != 3:
+        if want == OLDD and d.shape not in OLDD:
             return None, d.shape   # e.g. Co >= 256 on a small map: the wave-specialised kernel's layer, not this test's
-        assert d.shape == want, f"planner chose block shape {d.shape}, expected {want}"
+        assert d.shape in want, f"planner chose block shape {d.shape}, expected one of {want}"
         capi.call("stl_conv_forward", C.byref(d), stream())
         torch.cuda.synchronize()
-        assert capi.lib().stl_last_kernel().decode().startswith("conv_r2_kernel") == (want == 6)
+        assert capi.lib().stl_last_kernel().decode().startswith("conv_r2_kernel") == (d.shape in (6, 10))
         return dx, red
+    d32 = Co == 32 and Ci <= 32          # (the data gradient's roles: its Ci is this conv's Co)
+    OLDD = (8, 4) if d32 else (3,)
     for ops in ("my", "my+ad+mz", "ad", "none"):
-        dx3, r3 = dgrad("0", 3, ops)
+        if Co % 32 != 0:                 # a 16-channel data-gradient K has no instantiation on either kernel family of this test
+            break
+        dx3, r3 = dgrad("0", OLDD, ops)
         if dx3 is None:
             assert r3 == 9
             break
-        dx6, r6 = dgrad("3", 6, ops)
+        dx6, r6 = dgrad("31" if d32 else "3", (10,) if d32 else (6,), ops)
         nd = int((dx6 != dx3).sum())
         assert not torch.isnan(dx6.float()).any() and nd == 0, (ops, nd, float((dx6.float() - dx3.float()).abs().max()), float(dx3.float().abs().max()))
         assert torch.allclose(tot(r6), tot(r3), rtol=1e-5, atol=1e-3), ops

@@ -16,7 +16,7 @@ win = rows[adam[-2] + 1:adam[-1] + 1]; t0 = win[0]['s']
 def short(n):
     m = re.search(r'conv_core_kernelI(\w+?)Li(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)', n)
     if m: return f"conv<WM{m.group(3)}xWN{m.group(4)},MT{m.group(5)},q{m.group(8)}>"
-    for k in ('wgrad64', 'wgrad_ws', 'wgrad', 'conv_ws', 'conv1x1', 'conv_core', 'fuse_bwd', 'fuse_fwd', 'upsample_bwd', 'reduce_slabs', 'adam', 'head_bwd', 'head_fwd', 'mse'):
+    for k in ('wgrad64', 'wgrad_ws', 'wgrad', 'conv_ws', 'conv1x1', 'conv_r2', 'conv_core', 'fuse_bwd', 'fuse_fwd', 'upsample_bwd', 'reduce_slabs', 'adam', 'head_bwd', 'head_fwd', 'mse'):
         if k in n: return k
     return n[:30]
 last = {}; tot = collections.Counter(); cnt = collections.Counter()

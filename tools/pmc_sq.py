@@ -24,6 +24,9 @@ def load(d):
         if k == "conv_core":
             m = re.search(r"conv_core_kernelI\w+?Li\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELb([01])E", n)   # Q = 8th template argument
             k = "conv_q1" if (m and m.group(1) == "1") else "conv_q0"
+        if k == "conv_r2":   # conv_r2_kernel<T, TY, Q, ...>: Q = 3rd template argument (data gradient)
+            m = re.search(r"conv_r2_kernelI(?:DF16b|DF16_)(?:DF16b|DF16_|S\d*_)Lb([01])E", n)
+            k = "r2_q1" if (m and m.group(1) == "1") else "r2_q0"
         for c, v in per[i].items():
             if c != "name":
                 agg[k][c] += v
