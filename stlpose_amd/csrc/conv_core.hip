@@ -1078,9 +1078,10 @@ extern "C" int stl_conv_forward(const stl_conv* pp, void* stream) {
     // (256 for the 8-wave shapes, 1024 for the 4-wave ones); with ny channel blocks per pixel tile the
     // pixel dimension gets budget / ny (3x3 32->256 at 96x72: 102 -> 90 us; tools/conv_probe8.py)
     // 768 (not 1024) blocks for the 4-wave shapes: three resident blocks per CU leave room for the co-running kernels
-    // (16.62 -> 16.56 ms per step in round 2); 384 for the 8-wave 256 px x 32 co shape (two blocks per CU on half the CUs)
+    // (16.62 -> 16.56 ms per step in round 2); 432 for the 8-wave 256 px x 32 co shape (two blocks per CU on most CUs; the 864
+    // tiles of a 96 x 72 map at batch 32 are exactly two per block -- 384 blocks gave a quarter of them a third tile: 13.33 -> 13.28 ms)
     int cap = sh.thr == 512 ? 256 : 768;
-    if (plan.shape == 8) cap = 384;
+    if (plan.shape == 8) cap = getenv("STL_CONV_CAP8") ? atoi(getenv("STL_CONV_CAP8")) : 432;
     if (plan.shape == 5) cap = 512;   // two per CU
     if (plan.shape == 6) cap = 768;   // three per CU (<= 55 KB of LDS, <= 128 VGPRs)
     if (plan.shape == 10) cap = getenv("STL_R2_CAP10") ? atoi(getenv("STL_R2_CAP10")) : 768;   // <= 45 KB of LDS: three per CU

@@ -179,7 +179,13 @@ class Engine:
         self.bucket_mb = float(env("STLPOSE_BUCKET_MB", "64"))    # gradient bucket size (16 -> 32 MB: 16.79 -> 16.66 ms per step in round 2; 32 -> 64: 13.50 -> 13.42 in round 5)
         # block budget of a weight-gradient launch (a group shares it): 512 = two 8-wave blocks per CU, which hide each other's
         # tile latency (round 3, grouped launches: 128 / 256 / 512 / 768 blocks = 17.65 / 16.03 / 15.36 / 15.57 ms per step)
-        self.wgrad_blocks = int(env("STLPOSE_WGRAD_BLOCKS", "512"))
+        # Weight-gradient blocks per launch.  Round 5: 256 / 128 instead of 512 / 256 -- ONE 8-wave block (128 VGPRs) per CU, resp.
+        # 16-wave blocks (a whole CU's registers each) on HALF the CUs, so that the data-gradient chain always finds room: a
+        # persistent weight-gradient block holds its CU for the whole launch (45 - 70 us), and beside 500 / 256 of them a data
+        # gradient ran 2.3 - 4.5 x its own time while the weight gradient lost 3 - 17 % (tools/pair_probe.py,
+        # profiles/r05_pair_*.txt); beside 256 / 128 it runs 1.45 - 1.6 x.  Step: 13.30 -> 13.12 ms.
+        self.wgrad_blocks = int(env("STLPOSE_WGRAD_BLOCKS", "256"))
+        self.wgrad_blocks_wide = int(env("STLPOSE_WGRAD_BLOCKS_WIDE", str(self.wgrad_blocks // 2)))
         # members per grouped launch (round 3 at 256 blocks: 1 / 2 / 4 / 8 = 15.87 / 15.64 / 16.03 / 17.51; 4 at 512 blocks: 15.36)
         self.wgrad_group = int(env("STLPOSE_WGRAD_GROUP", "4"))
         # the 64-channel 3x3 blocks (16 waves, one per CU: 256 per launch): eight layers per launch keep the split-K slabs at the
@@ -668,7 +674,7 @@ class Engine:
         wg.TH, wg.TW = choose_tile(x.B, y.H, y.W, kstride, kks, self.esz, bn_cols=32, maxhalo=(256 if wide3 else 192) if ctile == 64 else 576)   # (256 halo pixels: two staging vectors per thread of the 16-wave block)
         npt = math.ceil(x.B * (y.H + 1) / wg.TH) * math.ceil(y.W / wg.TW)
         chunks = math.ceil(y.C / ctile) * math.ceil(x.C / ctile)
-        budget = self.wgrad_blocks // 2 if wide3 else self.wgrad_blocks
+        budget = self.wgrad_blocks_wide if wide3 else self.wgrad_blocks
         # The single-branch tail of backward (layer1, stem, transition1) is one serial data-gradient chain beside three idle
         # queues: a group there fills only when the chain has walked through ALL its members (every layer1 group completes
         # at the first block, i.e. at the very end of the step), so grouped weight gradients pile up behind the chain:

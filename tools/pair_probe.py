@@ -73,6 +73,9 @@ def main():
         "dgrad C=128 24x18 (mask_y)": pick(e.bwd_ops, lambda o: conv(o) and o[1].Ci == 128 and o[1].Co == 128 and o[1].ks == 3 and o[1].mask_y and not o[1].mask_z and not o[1].stuff),
         "forward C=64 48x36": pick(e.fwd_ops, lambda o: conv(o) and o[1].Ci == 64 and o[1].Co == 64 and o[1].Hi == 48 and o[1].ks == 3 and o[1].stride == 1 and o[1].src.mode == capi.SRC_BN),
         "forward C=128 24x18": pick(e.fwd_ops, lambda o: conv(o) and o[1].Ci == 128 and o[1].Co == 128 and o[1].ks == 3 and o[1].stride == 1 and o[1].src.mode == capi.SRC_BN),
+        "forward C=256 12x9": pick(e.fwd_ops, lambda o: conv(o) and o[1].Ci == 256 and o[1].Co == 256 and o[1].ks == 3 and o[1].stride == 1 and o[1].src.mode == capi.SRC_BN),
+        "dgrad C=256 12x9 (mask_y)": pick(e.bwd_ops, lambda o: conv(o) and o[1].Ci == 256 and o[1].Co == 256 and o[1].ks == 3 and o[1].mask_y and not o[1].mask_z and not o[1].stuff),
+        "dgrad C=32 96x72 (mask_y)": pick(e.bwd_ops, lambda o: conv(o) and o[1].Ci == 32 and o[1].Co == 32 and o[1].Hi == 96 and o[1].ks == 3 and o[1].mask_y and not o[1].mask_z and not o[1].stuff),
         "forward C=32 96x72": pick(e.fwd_ops, lambda o: conv(o) and o[1].Ci == 32 and o[1].Co == 32 and o[1].Hi == 96 and o[1].ks == 3 and o[1].stride == 1 and o[1].src.mode == capi.SRC_BN),
         "wgrad group C=32 96x72": pick(e.bwd_ops, lambda o: o[0] == "stl_conv_wgrad_group" and o[1].members[0].Ci == 32 and o[1].members[0].Hi == 96),
         "wgrad group C=64 48x36": pick(e.bwd_ops, lambda o: o[0] == "stl_conv_wgrad_group" and o[1].members[0].Ci == 64 and o[1].members[0].Hi == 48),
@@ -88,7 +91,8 @@ def main():
     pairs = [("dgrad C=64 48x36 (mask_y)", "wgrad group C=64 48x36"), ("dgrad C=64 48x36 (mask_y + addend + mask_z)", "wgrad group C=32 96x72"),
              ("dgrad C=64 48x36 (mask_y)", "dgrad C=128 24x18 (mask_y)"), ("forward C=64 48x36", "forward C=32 96x72"),
              ("forward C=64 48x36", "forward C=128 24x18"), ("dgrad C=128 24x18 (mask_y)", "wgrad group C=32 96x72"),
-             ("forward C=64 48x36", "forward C=64 48x36")]
+             ("forward C=64 48x36", "forward C=64 48x36"), ("dgrad C=32 96x72 (mask_y)", "wgrad group C=64 48x36"),
+             ("dgrad C=32 96x72 (mask_y)", "wgrad group C=32 96x72"), ("forward C=256 12x9", "forward C=32 96x72")]
     for a, b in pairs:
         ta, tb = time_pair(ops[a], ops[b], sa, sb)
         print(f"pair   {a:46s} {ta:7.2f} us (x{ta / alone[a]:.2f})  ||  {b:26s} {tb:7.2f} us (x{tb / alone[b]:.2f})   sum alone {alone[a] + alone[b]:6.1f}, pair wall/launch {max(ta, tb):6.1f}")
