@@ -62,6 +62,78 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(const stl_fuse p) {
     const uint32_t total = (uint32_t)p.B * p.H * p.W * VPC;
     bool flat = true;
     for (int t = 0; t < p.nterms; ++t) flat = flat && p.t[t].shift == 0;
+    const uint32_t nthr = gridDim.x * blockDim.x;
+    if (flat && p.nterms <= 2 && nthr % (uint32_t)VPC == 0) {
+        // Residual block ends (one or two terms of the output's resolution; round 5): the thread's channel group never changes
+        // (the grid's thread count is a multiple of the vectors per pixel), so its BatchNorm constants live in registers -- no
+        // division, no LDS read per element -- and two vectors per thread are in flight (the 113 MB sums of layer1 ran at 3.8 TB/s
+        // where a plain 2-read-1-write kernel reaches 6.1 on this chip, tools/hbm_ceiling.py).  Same arithmetic, same order.
+        const uint32_t v0 = blockIdx.x * blockDim.x + threadIdx.x;
+        const int c0 = (int)(v0 % (uint32_t)VPC) * 8;
+        float ca[2][8], cb[2][8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                ca[t][j] = t < p.nterms ? cs[(t * 2) * C + c0 + j] : 0.f;
+                cb[t][j] = t < p.nterms ? cs[(t * 2 + 1) * C + c0 + j] : 0.f;
+            }
+        const bool two = p.nterms == 2;
+        const bool bn0 = p.t[0].src.mode == STL_SRC_BN, bn1 = two && p.t[1].src.mode == STL_SRC_BN;
+        const bool r0 = p.t[0].src.relu, r1 = two && p.t[1].src.relu;
+        const void* x0 = p.t[0].src.x;
+        const void* x1 = two ? p.t[1].src.x : p.t[0].src.x;
+        auto term = [&](float* f, const float* a, const float* b, bool bn, bool relu) __attribute__((always_inline)) {
+            if (bn) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float u = fmaf(a[j], f[j], b[j]);
+                    f[j] = relu ? fmaxf(u, 0.f) : u;
+                }
+            }
+        };
+        for (uint32_t v = v0; v < total; v += 2 * nthr) {
+            const uint32_t w = v + nthr;
+            const bool hw = w < total;
+            float fa[8], fb[8], ga[8], gb[8];
+            load8<T>(x0, (size_t)v * 8, fa);
+            if (two) load8<T>(x1, (size_t)v * 8, fb);
+            if (hw) {
+                load8<T>(x0, (size_t)w * 8, ga);
+                if (two) load8<T>(x1, (size_t)w * 8, gb);
+            }
+            float s[8];
+            term(fa, ca[0], cb[0], bn0, r0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] = 0.f + fa[j];
+            if (two) {
+                term(fb, ca[1], cb[1], bn1, r1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += fb[j];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] = fmaxf(s[j], 0.f);
+            }
+            store8<T>(p.out, (size_t)v * 8, s);
+            if (hw) {
+                term(ga, ca[0], cb[0], bn0, r0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] = 0.f + ga[j];
+                if (two) {
+                    term(gb, ca[1], cb[1], bn1, r1);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s[j] += gb[j];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s[j] = fmaxf(s[j], 0.f);
+                }
+                store8<T>(p.out, (size_t)w * 8, s);
+            }
+        }
+        return;
+    }
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
         const uint32_t pi = v / (uint32_t)VPC;
         const int c0 = (int)(v - pi * VPC) * 8;

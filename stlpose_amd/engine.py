@@ -184,7 +184,8 @@ class Engine:
         # persistent weight-gradient block holds its CU for the whole launch (45 - 70 us), and beside 500 / 256 of them a data
         # gradient ran 2.3 - 4.5 x its own time while the weight gradient lost 3 - 17 % (tools/pair_probe.py,
         # profiles/r05_pair_*.txt); beside 256 / 128 it runs 1.45 - 1.6 x.  Step: 13.30 -> 13.12 ms.
-        self.wgrad_blocks = int(env("STLPOSE_WGRAD_BLOCKS", "256"))
+        # (16-bit plans; the fp32 kernels' blocks are half as many waves per CU to begin with: 512 stays -- 48.6 vs 50.1 ms per step)
+        self.wgrad_blocks = int(env("STLPOSE_WGRAD_BLOCKS", "256" if self.esz == 2 else "512"))
         self.wgrad_blocks_wide = int(env("STLPOSE_WGRAD_BLOCKS_WIDE", str(self.wgrad_blocks // 2)))
         # members per grouped launch (round 3 at 256 blocks: 1 / 2 / 4 / 8 = 15.87 / 15.64 / 16.03 / 17.51; 4 at 512 blocks: 15.36)
         self.wgrad_group = int(env("STLPOSE_WGRAD_GROUP", "4"))
