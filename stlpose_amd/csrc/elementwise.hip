@@ -134,6 +134,12 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(const stl_fuse p) {
         }
         return;
     }
+    // General form (up to four terms, upsampled ones among them): the terms' vectors are requested UP FRONT, unconditionally (absent
+    // terms alias term 0 and are never used) -- a run-time loop "load, transform, add" costs one memory round trip per term
+    const void* xp[4];
+    int sh[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xp[t] = p.t[t < p.nterms ? t : 0].src.x, sh[t] = p.t[t < p.nterms ? t : 0].shift;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
         const uint32_t pi = v / (uint32_t)VPC;
         const int c0 = (int)(v - pi * VPC) * 8;
@@ -144,25 +150,31 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(const stl_fuse p) {
             b = (int)(by / (uint32_t)p.H);
             y = (int)(by - (uint32_t)b * p.H);
         }
+        float f[4][8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int hs = p.H >> sh[t], ws = p.W >> sh[t];
+            const size_t off = flat ? (size_t)v * 8 : (((size_t)b * hs + (y >> sh[t])) * ws + (x >> sh[t])) * C + c0;
+            load8<T>(xp[t], off, f[t]);
+        }
         float s[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] = 0.f;
-        for (int t = 0; t < p.nterms; ++t) {
-            const stl_term& tm = p.t[t];
-            const int hs = p.H >> tm.shift, ws = p.W >> tm.shift;
-            const size_t off = flat ? (size_t)v * 8 : (((size_t)b * hs + (y >> tm.shift)) * ws + (x >> tm.shift)) * C + c0;
-            float f[8];
-            load8<T>(tm.src.x, off, f);
-            if (tm.src.mode == STL_SRC_BN) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float u = fmaf(cs[(t * 2) * C + c0 + j], f[j], cs[(t * 2 + 1) * C + c0 + j]);   // one rounding, as conv_common.inc's fma2
-                    // BN terms are rounded to the storage type like a materialised BN output would be
-                    f[j] = tm.src.relu ? fmaxf(u, 0.f) : u;
+        for (int t = 0; t < 4; ++t) {
+            if (t < p.nterms) {
+                const stl_term& tm = p.t[t];
+                if (tm.src.mode == STL_SRC_BN) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float u = fmaf(cs[(t * 2) * C + c0 + j], f[t][j], cs[(t * 2 + 1) * C + c0 + j]);   // one rounding, as conv_common.inc's fma2
+                        // BN terms are rounded to the storage type like a materialised BN output would be
+                        f[t][j] = tm.src.relu ? fmaxf(u, 0.f) : u;
+                    }
                 }
-            }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s[j] += f[j];
+                for (int j = 0; j < 8; ++j) s[j] += f[t][j];
+            }
         }
         if (p.relu) {
 #pragma unroll
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(const stl_fuse p) {
 // ---------------------------------------------------------------- fuse backward
 // T: the gradients dz / du; TY: the forward tensors z and bn[].x (f16 in the mixed mode)
 template <typename T, typename TY = T>
-__global__ void fuse_bwd_kernel(const stl_fuse_bwd p) {
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : 4) void fuse_bwd_kernel(const stl_fuse_bwd p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = p.C, VPC = C >> 3;
     float* mu = reinterpret_cast<float*>(smem);  // [nbn][2][C] mean, rstd
@@ -194,19 +206,39 @@ __global__ void fuse_bwd_kernel(const stl_fuse_bwd p) {
         for (int j = 0; j < 8; ++j) acc[s][j] = 0.f;
     const size_t total = (size_t)p.B * p.H * p.W * VPC;
     const int cg = threadIdx.x % VPC, c0 = cg * 8;  // (gridDim*blockDim) % VPC == 0 by construction
+    // Every tensor of an element is requested UP FRONT, unconditionally (absent operands alias dz[0]: same element size, the values
+    // are never used): written as "load, add, next load" under run-time operand counts the loop paid one memory round trip per
+    // operand -- up to nine in sequence, with four waves per CU -- and a 70 MB sum ran at 2.8 TB/s (round 5: 24.6 -> 18.6 us on the 96 x 72 x 32 branch tensor).
+    const void* dzp[4];
+    const void* yp[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dzp[k] = k < p.ngrads ? p.dz[k] : p.dz[0];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) yp[t] = t < p.nbn ? p.bn[t].x : p.dz[0];
+    const void* zp = p.relu ? p.z : p.dz[0];
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (size_t)gridDim.x * blockDim.x) {
         const size_t off = v * 8;
-        float d[8];
-        load8<T>(p.dz[0], off, d);
-        for (int k = 1; k < p.ngrads; ++k) {
-            float e[8];
-            load8<T>(p.dz[k], off, e);
+        float d[8], e1[8], e2[8], e3[8], z[8], y[4][8];
+        load8<T>(dzp[0], off, d);
+        load8<T>(dzp[1], off, e1);
+        load8<T>(dzp[2], off, e2);
+        load8<T>(dzp[3], off, e3);
+        load8<TY>(zp, off, z);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d[j] += e[j];
+        for (int t = 0; t < 4; ++t) load8<TY>(yp[t], off, y[t]);
+        if (p.ngrads > 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] += e1[j];
+        }
+        if (p.ngrads > 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] += e2[j];
+        }
+        if (p.ngrads > 3) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] += e3[j];
         }
         if (p.relu) {
-            float z[8];
-            load8<TY>(p.z, off, z);
 #pragma unroll
             for (int j = 0; j < 8; ++j) d[j] = z[j] > 0.f ? d[j] : 0.f;
         }
@@ -220,11 +252,9 @@ __global__ void fuse_bwd_kernel(const stl_fuse_bwd p) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (t < p.nbn) {
-                    float y[8];
-                    load8<TY>(p.bn[t].x, off, y);
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        acc[1 + t][j] += d[j] * (y[j] - mu[(t * 2) * C + c0 + j]) * mu[(t * 2 + 1) * C + c0 + j];
+                        acc[1 + t][j] += d[j] * (y[t][j] - mu[(t * 2) * C + c0 + j]) * mu[(t * 2 + 1) * C + c0 + j];
                 }
             }
         }
@@ -249,8 +279,8 @@ __global__ void fuse_bwd_kernel(const stl_fuse_bwd p) {
 }
 
 // ---------------------------------------------------------------- upsample backward
-template <typename T, typename TY = T>
-__global__ void upsample_bwd_kernel(const stl_upbwd p) {
+template <typename T, typename TY, int SHIFT>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const stl_upbwd p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = p.C, VPC = C >> 3;
     float* mu = reinterpret_cast<float*>(smem);  // [2][C]
@@ -266,30 +296,36 @@ __global__ void upsample_bwd_kernel(const stl_upbwd p) {
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[s][j] = 0.f;
-    const int f = 1 << p.shift, Hh = p.H << p.shift, Wh = p.W << p.shift;
-    const size_t total = (size_t)p.B * p.H * p.W * VPC;
+    // SHIFT is a template argument and the index arithmetic 32-bit (round 5): with run-time loop bounds the f x f source vectors of an
+    // output element were fetched ONE AT A TIME -- 4 / 16 / 64 memory round trips in sequence -- behind 64-bit divisions.  Now one row
+    // of f vectors (and the BatchNorm input) is in flight at a time; the summation order (rows outer, columns inner) is unchanged.
+    constexpr int F = 1 << SHIFT;
+    const uint32_t Wh = (uint32_t)p.W << SHIFT, Hh = (uint32_t)p.H << SHIFT;
+    const uint32_t total = (uint32_t)p.B * p.H * p.W * VPC;
     const int cg = threadIdx.x % VPC, c0 = cg * 8;
-    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (size_t)gridDim.x * blockDim.x) {
-        const size_t pi = v / VPC;
-        const int x = (int)(pi % p.W);
-        const size_t by = pi / p.W;
-        const int y = (int)(by % p.H), b = (int)(by / p.H);
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
+        const uint32_t pi = v / (uint32_t)VPC;
+        const uint32_t by = pi / (uint32_t)p.W, x = pi - by * p.W;
+        const uint32_t b = by / (uint32_t)p.H, y = by - b * p.H;
+        float yv[8];
+        load8<TY>(p.bn.x, (size_t)pi * C + c0, yv);
         float s[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] = 0.f;
-        for (int dy = 0; dy < f; ++dy)
-            for (int dx = 0; dx < f; ++dx) {
-                const size_t off = (((size_t)b * Hh + (y * f + dy)) * Wh + (x * f + dx)) * C + c0;
-                float d[8];
-                load8<T>(p.du, off, d);
+        const size_t row0 = ((size_t)(b * Hh + y * F) * Wh + x * F) * C + c0;
+#pragma unroll(SHIFT == 1 ? 2 : 1)
+        for (int dy = 0; dy < F; ++dy) {   // (SHIFT >= 2: one row at a time -- unrolled, the compiler requests all F x F vectors at once: 150 - 210 registers)
+            float d[F][8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s[j] += d[j];
-            }
+            for (int dx = 0; dx < F; ++dx) load8<T>(p.du, row0 + ((size_t)dy * Wh + dx) * C, d[dx]);
+#pragma unroll
+            for (int dx = 0; dx < F; ++dx)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += d[dx][j];
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] = round_to<T>(s[j]);
-        store8<T>(p.dt, pi * C + c0, s);
-        float yv[8];
-        load8<TY>(p.bn.x, pi * C + c0, yv);
+        store8<T>(p.dt, (size_t)pi * C + c0, s);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             acc[0][j] += s[j];
@@ -649,9 +685,33 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* master, T
             const int co0 = (tile / tci) * 32, ci0 = (tile % tci) * 32;
             const int nco = min(32, e.Co - co0), nci = min(32, e.Ci - ci0), seg = nci * t;
             __syncthreads();
-            for (int r = threadIdx.x >> 6; r < nco; r += 4) {   // one wave per co row: contiguous, division-free
-                const float* row = src0 + ((int64_t)(co0 + r) * e.Ci + ci0) * t;
-                for (int c = threadIdx.x & 63; c < seg; c += 64) st[r * pitch + c] = row[c];
+            if (((e.src_off & 3) | (int)((uintptr_t)master & 15)) == 0) {
+                // 16-byte loads, all of a thread's (up to nine) in flight at once: (row, quad) tasks over the block.  (Round 5: the
+                // 4-byte row walk had one small load per lane in flight -- 94 us for 114 MB in + 114 MB out.)  Rows start on
+                // 16-byte boundaries: Ci and ci0 * taps are multiples of 4.
+                const int nv = seg >> 2, ntask = nco * nv;
+                float4 buf[9];
+#pragma unroll
+                for (int u = 0; u < 9; ++u) {
+                    const int i = threadIdx.x + u * 256;
+                    const bool ok = i < ntask;
+                    const int r = ok ? i / nv : 0, q = ok ? i - r * nv : 0;
+                    buf[u] = *reinterpret_cast<const float4*>(src0 + ((int64_t)(co0 + r) * e.Ci + ci0) * t + 4 * q);
+                }
+#pragma unroll
+                for (int u = 0; u < 9; ++u) {
+                    const int i = threadIdx.x + u * 256;
+                    if (i < ntask) {
+                        const int r = i / nv, q = i - r * nv;
+                        float* d = st + r * pitch + 4 * q;
+                        d[0] = buf[u].x, d[1] = buf[u].y, d[2] = buf[u].z, d[3] = buf[u].w;
+                    }
+                }
+            } else {
+                for (int r = threadIdx.x >> 6; r < nco; r += 4) {   // one wave per co row: contiguous, division-free
+                    const float* row = src0 + ((int64_t)(co0 + r) * e.Ci + ci0) * t;
+                    for (int c = threadIdx.x & 63; c < seg; c += 64) st[r * pitch + c] = row[c];
+                }
             }
             __syncthreads();
             T v[4];
@@ -1091,7 +1151,7 @@ extern "C" int stl_fuse_backward(const stl_fuse_bwd* pp, void* stream) {
     const size_t total = (size_t)p.B * p.H * p.W * (p.C / 8);
     // grid: 256 blocks measured best end to end for the branch tensors (fewer statistics atomics, less
     // contention with co-running kernels); the 113 MB layer1 tensors need more loads in flight
-    int cap = (int)(total / (size_t)(bd * 16));
+    int cap = (int)(total / (size_t)(bd * 16));   // (8 / 4 vectors per thread, i.e. 2 / 4 x the blocks: 13.09 / 13.20 vs 13.07 ms per step, round 5)
     cap = cap < 256 ? 256 : (cap > 1024 ? 1024 : cap);
     int nb = nblocks_for(total, bd, cap);
     const size_t lds = (size_t)(p.nbn > 0 ? p.nbn : 1) * 2 * p.C * 4 + (size_t)bd * 2 * 8 * 4;
@@ -1109,7 +1169,7 @@ extern "C" int stl_fuse_backward(const stl_fuse_bwd* pp, void* stream) {
 extern "C" int stl_upsample_backward(const stl_upbwd* pp, void* stream) {
     const stl_upbwd& p = *pp;
     STL_CHECK(p.C % 8 == 0 && p.C > 0 && p.C <= 1024, "upsample_bwd: C=%d", p.C);
-    STL_CHECK(p.shift >= 1 && p.shift <= 4, "upsample_bwd: shift %d", p.shift);
+    STL_CHECK(p.shift >= 1 && p.shift <= 3, "upsample_bwd: shift %d (1 .. 3)", p.shift);
     STL_CHECK(p.du && p.dt && p.bn.x && p.bn.stats && p.rstats, "upsample_bwd: null pointer");
     const int bd = stat_block(p.C);
     const size_t total = (size_t)p.B * p.H * p.W * (p.C / 8);
@@ -1120,12 +1180,22 @@ extern "C" int stl_upsample_backward(const stl_upbwd* pp, void* stream) {
     int nb = nblocks_for(total, bd, cap);
     const size_t lds = (size_t)2 * p.C * 4 + (size_t)bd * 2 * 8 * 4;
     STL_CHECK(p.ydtype == 0 || p.ydtype == p.dtype || (p.dtype == STL_BF16 && p.ydtype == STL_F16), "upsample_bwd: ydtype %d does not go with dtype %d", p.ydtype, p.dtype);
+    STL_CHECK(total * 8 < (1ull << 31) && ((size_t)p.B * (p.H << p.shift) * (p.W << p.shift) * p.C) < (1ull << 32),
+              "upsample_bwd: tensors of 2^31 or more elements are not supported (32-bit index arithmetic)");
+#define STL_UP(TT, TYY)                                                                                         \
+    do {                                                                                                        \
+        if (p.shift == 1) STL_LAUNCH((upsample_bwd_kernel<TT, TYY, 1>), dim3(nb), dim3(bd), lds, ST, p);        \
+        else if (p.shift == 2) STL_LAUNCH((upsample_bwd_kernel<TT, TYY, 2>), dim3(nb), dim3(bd), lds, ST, p);   \
+        else if (p.shift == 3) STL_LAUNCH((upsample_bwd_kernel<TT, TYY, 3>), dim3(nb), dim3(bd), lds, ST, p);   \
+        else return stl_set_error("upsample_bwd: shift %d has no instantiation (1 .. 3)", p.shift);             \
+    } while (0)
     if (p.dtype == STL_BF16 && p.ydtype == STL_F16)
-        STL_LAUNCH((upsample_bwd_kernel<__bf16, f16>), dim3(nb), dim3(bd), lds, ST, p);
+        STL_UP(__bf16, f16);
     else if (p.dtype == STL_BF16)
-        STL_LAUNCH(upsample_bwd_kernel<__bf16>, dim3(nb), dim3(bd), lds, ST, p);
+        STL_UP(__bf16, __bf16);
     else
-        STL_LAUNCH(upsample_bwd_kernel<float>, dim3(nb), dim3(bd), lds, ST, p);
+        STL_UP(float, float);
+#undef STL_UP
     STL_LAUNCH_CHECK("upsample_backward");
     return 0;
 }
