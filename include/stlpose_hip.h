@@ -191,7 +191,10 @@ int stl_gaussian_targets(const float* joints_xy, const float* vis, float* target
                          int Hh, int Wh, float stride_x, float stride_y, float sigma, void* stream);
 
 /* PersonMSELoss forward+backward (reference lib/loss.py:71-94):
- * loss = 0.5*mean(((o-t)*w)^2) over all B*J*H*W;  dout = (o-t)*w^2 / (B*J*H*W) * gscale. */
+ * loss = 0.5*mean(((o-t)*w)^2) over all B*J*H*W;  dout = (o-t)*w^2 / (B*J*H*W) * gscale.
+ * loss == NULL: only dout and the per-block partial sums are written; the caller finishes the scalar with
+ * stl_sum_partials(partial, nblk, 0.5 / (B*J*H*W), loss, 0, stream) whenever it likes (the train step: behind the
+ * backward program, so that the one-block sum does not sit in front of the head's gradient). */
 int stl_mse_loss(const float* out, const float* target, const float* tweight, float* dout,
                  double* partial, int nblk, float* loss, int B, int J, int HW, float gscale, void* stream);
 

@@ -441,14 +441,18 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const void* x, const floa
         }
 #pragma unroll
         for (int j = 0; j < J; ++j) sd[j * SDP + tid] = d[j];
-        for (int c0 = 0; c0 < Ci; c0 += 8) {
-            float f[8], gx[8];
-            if (pi < P) {
-                load8<TY>(x, pi * Ci + c0, f);
-            } else {
+        // the pixel's Ci <= 64 activations: all (up to eight) vectors requested up front (a run-time loop "load, use" pays one memory
+        // round trip per vector; static indices keep the array in registers)
+        float fx[8][8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) f[q] = 0.f;
-            }
+        for (int v8 = 0; v8 < 8; ++v8) load8<TY>(x, (pi < P ? pi * Ci : 0) + (v8 * 8 < Ci ? v8 * 8 : 0), fx[v8]);
+#pragma unroll
+        for (int v8 = 0; v8 < 8; ++v8) {
+            const int c0 = v8 * 8;
+            if (c0 >= Ci) break;
+            float f[8], gx[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) f[q] = pi < P ? fx[v8][q] : 0.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 sx[tid * (Ci + 1) + c0 + q] = f[q];
@@ -1270,10 +1274,11 @@ extern "C" int stl_sum_partials(const double* partial, int n, double scale, floa
 
 extern "C" int stl_mse_loss(const float* out, const float* target, const float* tweight, float* dout, double* partial,
                             int nblk, float* loss, int B, int J, int HW, float gscale, void* stream) {
-    STL_CHECK(out && target && tweight && partial && loss && nblk >= 1, "mse: null pointer");
+    STL_CHECK(out && target && tweight && partial && nblk >= 1, "mse: null pointer");
     const size_t n = (size_t)B * J * HW;
     STL_LAUNCH(mse_kernel, dim3(nblk), dim3(256), 0, ST, out, target, tweight, dout, partial, n, HW, gscale / (float)n);
     STL_LAUNCH_CHECK("mse_loss");
+    if (!loss) return 0;   // the caller sums the partials later: stl_sum_partials(partial, nblk, 0.5 / (B * J * HW), loss, 0, stream)
     return stl_sum_partials(partial, nblk, 0.5 / (double)n, loss, 0, stream);
 }
 

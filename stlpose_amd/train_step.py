@@ -137,11 +137,9 @@ class TrainStep:
         self._prepped = False
         e.forward(st, update_running=update_running)
         B, J = e.out.shape[:2]
+        HW = e.out[0, 0].numel()
         capi.call("stl_mse_loss", e.out.data_ptr(), self.target.data_ptr(), self.tweight.data_ptr(), e.dout.data_ptr(),
-                  self._partial.data_ptr(), self._nblk, self.loss.data_ptr(), B, J, e.out[0, 0].numel(),
-                  self._loss_scale, st)
-        if self._loss_scale != 1.0 or self._loss_offset != 0.0:   # the kernel scales only dL/dout
-            self.loss.mul_(self._loss_scale).add_(self._loss_offset)
+                  self._partial.data_ptr(), self._nblk, None, B, J, HW, self._loss_scale, st)   # (the scalar: behind backward, below)
         if fused_optim:
             capi.call("stl_optim_begin_step", self.step_count.data_ptr(), self.eng.overflow.data_ptr(), st)
         # per-bucket issue while backward is being enqueued: RCCL only ("nccl": the collective is a kernel enqueued on the
@@ -149,6 +147,11 @@ class TrainStep:
         dp_on = self.dp is not None and (self.world > 1 or self._force_dp) and not self.use_graph and self._dp_rccl
         e.backward(st, fused_optim=fused_optim, on_bucket=self._issue_bucket if dp_on else None)
         self._buckets_issued = dp_on
+        # the loss scalar (a one-block sum of the per-block partials): enqueued BEHIND the backward program -- between the loss
+        # kernel and the head's gradient it was 16 us of a single resident block at a point where nothing else can run
+        capi.call("stl_sum_partials", self._partial.data_ptr(), self._nblk, 0.5 / float(B * J * HW), self.loss.data_ptr(), 0, st)
+        if self._loss_scale != 1.0 or self._loss_offset != 0.0:   # the kernel scales only dL/dout
+            self.loss.mul_(self._loss_scale).add_(self._loss_offset)
         if fused_optim:
             self._prepped = True   # every bucket's kernel-layout weights were refreshed inside the program
 
