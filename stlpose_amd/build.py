@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(HERE, "..", "include")
 LIB = os.path.join(HERE, "libstlpose_hip.so")
-# (source, object tag, extra flags): conv_core and wgrad are compiled once per dtype (-DSTL_DT) so that their kernel
+# (source, object tag, extra flags): conv_core and wgrad are compiled once per dtype (-DSTL_DT = number of the TRANSLATION UNIT:
+# 0 fp32, 1 bf16 + C ABI, 3 f16 -- not an element-type code, STL_F16 is 2) so that their kernel
 # instantiations build in parallel
 UNITS = [("capi.hip", "capi", []), ("conv_core.hip", "conv_core_bf16", ["-DSTL_DT=1"]), ("conv_core.hip", "conv_core_f32", ["-DSTL_DT=0"]),
          ("conv_core.hip", "conv_core_f16", ["-DSTL_DT=3"]),

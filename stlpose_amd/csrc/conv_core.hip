@@ -21,8 +21,10 @@
 #include <type_traits>
 #include "common.cuh"
 
-// The file is compiled twice by stlpose_amd/build.py -- -DSTL_DT=1: the bf16 kernels + the C ABI entry points, -DSTL_DT=0: the
-// fp32 kernels -- so that the two halves of its ~130 kernel instantiations build in parallel; STL_DT=2 (default) = one unit.
+// The file is compiled three times by stlpose_amd/build.py -- -DSTL_DT=1: the bf16 kernels + the C ABI entry points, -DSTL_DT=0: the
+// fp32 kernels, -DSTL_DT=3: the f16 forward kernels -- so that its kernel instantiations build in parallel; STL_DT=2 (default) =
+// one unit with everything.  NOTE: STL_DT numbers TRANSLATION UNITS, not element types (the element type STL_F16 is 2, the f16
+// unit is 3): only the STL_HAS_* macros below may look at it.
 #ifndef STL_DT
 #define STL_DT 2
 #endif
@@ -938,8 +940,8 @@ Plan choose_plan(const stl_conv& p, int ck) {
 
 }  // namespace
 
-static int ydtype_of(const stl_conv& p) { return (p.dtype == STL_BF16 && p.ydtype == STL_F16) ? STL_F16 : p.dtype; }   // 0 = same as dtype
 #if STL_HAS_BF16
+static int ydtype_of(const stl_conv& p) { return (p.dtype == STL_BF16 && p.ydtype == STL_F16) ? STL_F16 : p.dtype; }   // 0 = same as dtype
 int stl_conv_backend_bf16(int path, const stl_conv& p, const ConvK& k, int shape, int nva, dim3 grid, size_t lds, hipStream_t st) {
     if (ydtype_of(p) == STL_F16) return conv_backend<__bf16, f16>(path, p, k, shape, nva, grid, lds, st);   // mixed-mode data gradient
     return conv_backend<__bf16, __bf16>(path, p, k, shape, nva, grid, lds, st);
