@@ -290,10 +290,19 @@ def extra_eval_path(dev, batches=10, batch=32, H=384, W=288, persons_per_image=4
     ev = Evaluator(model, device=dev, flip=True)
     ev.evaluate_model(loader(2))   # warm-up: plan + lazy kernel attributes
     torch.cuda.synchronize()
+    prof = None
+    if os.environ.get("STL_BENCH_EVAL_PROFILE"):   # where does the host spend this leg? (cProfile -> stderr)
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     res = ev.evaluate_model(loader(batches))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(14)
     n = batches * batch
     tf = n / dt * 2 * 34.403e9 / 1e12     # two forward passes per image (F_fwd 34.403 GFLOP at 384x288)
     out = dict(metric="images/sec evaluation path HRNet-W32 384x288 bs=32: flip-test forward x2 + flip_merge + loss + PCK + final_preds + rescoring / OKS-NMS",

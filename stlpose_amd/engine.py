@@ -195,6 +195,8 @@ class Engine:
         self.skip_wgrad = env("STLPOSE_SKIP_WGRAD", "0") != "0"   # calibration only (wrong numerics): no weight-gradient launches
         # STLPOSE_GRAPH=1: replay each program as ONE explicit HIP graph (csrc/program.hip: kernel nodes + the planner's
         # dependencies) instead of launches and events on four streams
+        # Replay as ONE explicit HIP graph (stl_program_graph_build) instead of launches + events: slower for training plans (16.78 vs
+        # 14.53 ms per step, round 4) and for inference plans (4.37 vs 4.20 ms per W32 384x288 bs 32 forward, round 5) -- opt-in.
         self.graph_mode = env("STLPOSE_GRAPH", "0") != "0"
         self._graphs = set()
         self._poison = env("STLPOSE_POISON", "0") != "0"          # debug: planned buffers start as NaNs (see _alloc)
