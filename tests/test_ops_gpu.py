@@ -547,6 +547,92 @@ def test_fuse_forward_backward_upsample(dt):
         assert relerr(dy, ref) < tol * 3
 
 
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("Cc,nterms,ngrads,nbn", [(32, 1, 1, 0), (32, 2, 3, 1), (64, 2, 4, 3), (48, 2, 2, 2), (256, 2, 1, 1), (32, 4, 2, 1)])
+def test_elementwise_sums_every_operand_count(dt, Cc, nterms, ngrads, nbn):
+    """Round 5 rewrote the sum kernels so that every operand of an element is requested up front (absent operands alias operand
+    0): the one- / two-term residual form of stl_fuse_forward (register-resident constants; C = 48 is NOT a divisor of the grid's
+    thread count and takes the general form), the general form with upsampled terms, stl_fuse_backward with 1 .. 4 gradient
+    contributions and 0 .. 3 BatchNorm inputs, stl_upsample_backward for shifts 1 .. 3 -- each against plain torch."""
+    code, td, tol = DT[dt]
+    B, H, W = 2, 16, 24
+    g = torch.Generator(device="cuda").manual_seed(7 + Cc + nterms)
+    terms_nchw, p = [], capi.Fuse()
+    p.dtype, p.B, p.H, p.W, p.C, p.nterms, p.relu = code, B, H, W, Cc, nterms, 1
+    keep, z = [], 0
+    for t in range(nterms):
+        sh = 0 if nterms <= 2 else t % 4          # the four-term case: shifts 0, 1, 2, 3 (upsampled BatchNorm terms)
+        h, w = H >> sh, W >> sh
+        x = nhwc(torch.randn(B, Cc, h, w, device="cuda", generator=g) * (1 + t) + 0.3 * t, td)
+        xf = x.float().permute(0, 3, 1, 2)
+        if t == 0 and nterms > 1:                 # a plain term
+            p.t[t].src.x, p.t[t].src.mode = x.data_ptr(), capi.SRC_PLAIN
+            v = xf
+        else:
+            ga, be = torch.rand(Cc, device="cuda", generator=g) + 0.5, torch.rand(Cc, device="cuda", generator=g) - 0.5
+            st = stats_of(x, Cc)
+            p.t[t].src = bn_src(x, st, ga, be, B * h * w, False)
+            v = F.batch_norm(xf, None, None, ga, be, True, 0.1, EPS)
+            keep += [ga, be, st]
+        p.t[t].shift = sh
+        if sh:
+            v = F.interpolate(v, scale_factor=1 << sh, mode="nearest")
+        z = z + v
+        keep.append(x)
+    zk = torch.empty(B * H * W * Cc, device="cuda", dtype=td)
+    p.out = zk.data_ptr()
+    capi.call("stl_fuse_forward", C.byref(p), stream())
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc(zk, B, H, W, Cc), F.relu(z)) < tol
+    # ---- backward: ngrads contributions, ReLU mask, nbn BatchNorm inputs
+    ds = [nhwc(torch.randn(B, Cc, H, W, device="cuda", generator=g), td) for _ in range(ngrads)]
+    ys = [nhwc(torch.randn(B, Cc, H, W, device="cuda", generator=g) * 1.5 + 0.2, td) for _ in range(nbn)]
+    q = capi.FuseBwd()
+    q.dtype, q.B, q.H, q.W, q.C, q.ngrads, q.relu, q.nbn = code, B, H, W, Cc, ngrads, 1, nbn
+    for i, d in enumerate(ds):
+        q.dz[i] = d.data_ptr()
+    q.z = zk.data_ptr()
+    du = torch.empty_like(zk)
+    q.du = du.data_ptr()
+    rs, ones = [], torch.ones(Cc, device="cuda")
+    for i, y in enumerate(ys):
+        sti = stats_of(y, Cc)
+        q.bn[i] = bn_src(y, sti, ones, ones, B * H * W, False)
+        r = torch.zeros(capi.NSHARD * 2 * Cc, dtype=torch.float64, device="cuda")
+        q.rstats[i] = r.data_ptr()
+        rs.append(r)
+        keep.append(sti)
+    capi.call("stl_fuse_backward", C.byref(q), stream())
+    torch.cuda.synchronize()
+    dsum = sum(d.float() for d in ds) * (zk.float() > 0)
+    assert relerr(du.float(), dsum) < tol
+    duf = du.float().view(-1, Cc).double()
+    for y, r in zip(ys, rs):
+        yf = y.float().view(-1, Cc).double()
+        mean, rstd = yf.mean(0), 1.0 / torch.sqrt(yf.var(0, unbiased=False) + EPS)
+        got = r.view(capi.NSHARD, 2, Cc).sum(0)
+        assert relerr(got[0], duf.sum(0)) < tol and relerr(got[1], (duf * (yf - mean) * rstd).sum(0)) < tol * 3
+    # ---- upsample backward, shifts 1 .. 3
+    for sh in (1, 2, 3):
+        h, w = H >> sh, W >> sh
+        yb = nhwc(torch.randn(B, Cc, h, w, device="cuda", generator=g), td)
+        stb = stats_of(yb, Cc)
+        u = capi.UpBwd()
+        u.dtype, u.B, u.H, u.W, u.C, u.shift = code, B, h, w, Cc, sh
+        dtl = torch.empty(B * h * w * Cc, device="cuda", dtype=td)
+        r2 = torch.zeros(capi.NSHARD * 2 * Cc, dtype=torch.float64, device="cuda")
+        u.du, u.dt, u.bn, u.rstats = du.data_ptr(), dtl.data_ptr(), bn_src(yb, stb, ones, ones, B * h * w, False), r2.data_ptr()
+        capi.call("stl_upsample_backward", C.byref(u), stream())
+        torch.cuda.synchronize()
+        ref = F.avg_pool2d(from_nhwc(du, B, H, W, Cc), 1 << sh) * float(1 << (2 * sh))
+        assert relerr(from_nhwc(dtl, B, h, w, Cc), ref) < tol
+        yf = yb.float().view(-1, Cc).double()
+        mean, rstd = yf.mean(0), 1.0 / torch.sqrt(yf.var(0, unbiased=False) + EPS)
+        dtf = dtl.float().view(-1, Cc).double()
+        got = r2.view(capi.NSHARD, 2, Cc).sum(0)
+        assert relerr(got[0], dtf.sum(0)) < tol and relerr(got[1], (dtf * (yf - mean) * rstd).sum(0)) < tol * 3
+
+
 def test_head_mse_argmax_golden(golden_dir):
     import os
     g6 = np.load(os.path.join(golden_dir, "g6_mse.npz"))
