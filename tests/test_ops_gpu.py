@@ -604,8 +604,8 @@ def test_elementwise_sums_every_operand_count(dt, Cc, nterms, ngrads, nbn):
         keep.append(sti)
     capi.call("stl_fuse_backward", C.byref(q), stream())
     torch.cuda.synchronize()
-    dsum = sum(d.float() for d in ds) * (zk.float() > 0)
-    assert relerr(du.float(), dsum) < tol
+    dsum = sum(d.float() for d in ds) * (zk.view(B, H, W, Cc).float() > 0)
+    assert relerr(du.view(B, H, W, Cc).float(), dsum) < tol
     duf = du.float().view(-1, Cc).double()
     for y, r in zip(ys, rs):
         yf = y.float().view(-1, Cc).double()
