@@ -62,84 +62,6 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(const stl_fuse p) {
     const uint32_t total = (uint32_t)p.B * p.H * p.W * VPC;
     bool flat = true;
     for (int t = 0; t < p.nterms; ++t) flat = flat && p.t[t].shift == 0;
-    const uint32_t nthr = gridDim.x * blockDim.x;
-    if (flat && p.nterms <= 2 && nthr % (uint32_t)VPC == 0) {
-        // Residual block ends (one or two terms of the output's resolution; round 5): the thread's channel group never changes
-        // (the grid's thread count is a multiple of the vectors per pixel), so its BatchNorm constants live in registers -- no
-        // division, no LDS read per element -- and two vectors per thread are in flight (the 113 MB sums of layer1 ran at 3.8 TB/s
-        // where a plain 2-read-1-write kernel reaches 6.1 on this chip, tools/hbm_ceiling.py).  Same arithmetic, same order.
-        const uint32_t v0 = blockIdx.x * blockDim.x + threadIdx.x;
-        const int c0 = (int)(v0 % (uint32_t)VPC) * 8;
-        float ca[2][8], cb[2][8];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                ca[t][j] = t < p.nterms ? cs[(t * 2) * C + c0 + j] : 0.f;
-                cb[t][j] = t < p.nterms ? cs[(t * 2 + 1) * C + c0 + j] : 0.f;
-            }
-        const bool two = p.nterms == 2;
-        const bool bn0 = p.t[0].src.mode == STL_SRC_BN, bn1 = two && p.t[1].src.mode == STL_SRC_BN;
-        const bool r0 = p.t[0].src.relu, r1 = two && p.t[1].src.relu;
-        const void* x0 = p.t[0].src.x;
-        const void* x1 = two ? p.t[1].src.x : p.t[0].src.x;
-        auto term = [&](float* f, const float* a, const float* b, bool bn, bool relu) __attribute__((always_inline)) {
-            if (bn) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float u = fmaf(a[j], f[j], b[j]);
-                    f[j] = relu ? fmaxf(u, 0.f) : u;
-                }
-            }
-        };
-        for (uint32_t v = v0; v < total; v += 2 * nthr) {
-            const uint32_t w = v + nthr;
-            const bool hw = w < total;
-            float fa[8], fb[8], ga[8], gb[8];
-            load8<T>(x0, (size_t)v * 8, fa);
-            if (two) load8<T>(x1, (size_t)v * 8, fb);
-            if (hw) {
-                load8<T>(x0, (size_t)w * 8, ga);
-                if (two) load8<T>(x1, (size_t)w * 8, gb);
-            }
-            float s[8];
-            term(fa, ca[0], cb[0], bn0, r0);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s[j] = 0.f + fa[j];
-            if (two) {
-                term(fb, ca[1], cb[1], bn1, r1);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s[j] += fb[j];
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s[j] = fmaxf(s[j], 0.f);
-            }
-            store8<T>(p.out, (size_t)v * 8, s);
-            if (hw) {
-                term(ga, ca[0], cb[0], bn0, r0);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s[j] = 0.f + ga[j];
-                if (two) {
-                    term(gb, ca[1], cb[1], bn1, r1);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) s[j] += gb[j];
-                }
-                if (p.relu) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) s[j] = fmaxf(s[j], 0.f);
-                }
-                store8<T>(p.out, (size_t)w * 8, s);
-            }
-        }
-        return;
-    }
-    // General form (up to four terms, upsampled ones among them): the terms' vectors are requested UP FRONT, unconditionally (absent
-    // terms alias term 0 and are never used) -- a run-time loop "load, transform, add" costs one memory round trip per term
-    const void* xp[4];
-    int sh[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) xp[t] = p.t[t < p.nterms ? t : 0].src.x, sh[t] = p.t[t < p.nterms ? t : 0].shift;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
         const uint32_t pi = v / (uint32_t)VPC;
         const int c0 = (int)(v - pi * VPC) * 8;
@@ -150,37 +72,121 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(const stl_fuse p) {
             b = (int)(by / (uint32_t)p.H);
             y = (int)(by - (uint32_t)b * p.H);
         }
-        float f[4][8];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int hs = p.H >> sh[t], ws = p.W >> sh[t];
-            const size_t off = flat ? (size_t)v * 8 : (((size_t)b * hs + (y >> sh[t])) * ws + (x >> sh[t])) * C + c0;
-            load8<T>(xp[t], off, f[t]);
-        }
         float s[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] = 0.f;
+        for (int t = 0; t < p.nterms; ++t) {
+            const stl_term& tm = p.t[t];
+            const int hs = p.H >> tm.shift, ws = p.W >> tm.shift;
+            const size_t off = flat ? (size_t)v * 8 : (((size_t)b * hs + (y >> tm.shift)) * ws + (x >> tm.shift)) * C + c0;
+            float f[8];
+            load8<T>(tm.src.x, off, f);
+            if (tm.src.mode == STL_SRC_BN) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (t < p.nterms) {
-                const stl_term& tm = p.t[t];
-                if (tm.src.mode == STL_SRC_BN) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float u = fmaf(cs[(t * 2) * C + c0 + j], f[t][j], cs[(t * 2 + 1) * C + c0 + j]);   // one rounding, as conv_common.inc's fma2
-                        // BN terms are rounded to the storage type like a materialised BN output would be
-                        f[t][j] = tm.src.relu ? fmaxf(u, 0.f) : u;
-                    }
+                for (int j = 0; j < 8; ++j) {
+                    float u = fmaf(cs[(t * 2) * C + c0 + j], f[j], cs[(t * 2 + 1) * C + c0 + j]);   // one rounding, as conv_common.inc's fma2
+                    // BN terms are rounded to the storage type like a materialised BN output would be
+                    f[j] = tm.src.relu ? fmaxf(u, 0.f) : u;
                 }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s[j] += f[t][j];
             }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += f[j];
         }
         if (p.relu) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) s[j] = fmaxf(s[j], 0.f);
         }
         store8<T>(p.out, (size_t)v * 8, s);
+    }
+}
+
+// One- / two-term sums of the output's resolution over LARGE tensors (the 113 MB residual block ends of layer1; round 5): the
+// thread's channel group never changes (the grid's thread count is a multiple of the vectors per pixel), so its BatchNorm constants
+// live in registers -- no division, no LDS read per element -- and two vectors per thread are in flight: 80 -> 70 us where a plain
+// 2-read-1-write kernel reaches 6.1 TB/s (tools/hbm_ceiling.py).  A kernel of its OWN: at 73 registers the sum kernel loses a
+// quarter of its resident waves, and the 66 small two-term sums of a step (14 - 42 MB) ran 2 us SLOWER each with this code inline.
+// Same arithmetic, same order as fuse_fwd_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_flat_big_kernel(const stl_fuse p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* cs = reinterpret_cast<float*>(smem);  // [nterms][2][C]
+    const int C = p.C, VPC = C >> 3;
+    for (int e = threadIdx.x; e < p.nterms * C; e += blockDim.x) {
+        const int t = e / C, c = e - t * C;
+        float a, b, cc;
+        src_consts(p.t[t].src, c, C, a, b, cc);
+        cs[(t * 2) * C + c] = a, cs[(t * 2 + 1) * C + c] = b;
+    }
+    __syncthreads();
+    const uint32_t total = (uint32_t)p.B * p.H * p.W * VPC;
+    const uint32_t nthr = gridDim.x * blockDim.x;
+    // Residual block ends (one or two terms of the output's resolution; round 5): the thread's channel group never changes
+    // (the grid's thread count is a multiple of the vectors per pixel), so its BatchNorm constants live in registers -- no
+    // division, no LDS read per element -- and two vectors per thread are in flight (the 113 MB sums of layer1 ran at 3.8 TB/s
+    // where a plain 2-read-1-write kernel reaches 6.1 on this chip, tools/hbm_ceiling.py).  Same arithmetic, same order.
+    const uint32_t v0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c0 = (int)(v0 % (uint32_t)VPC) * 8;
+    float ca[2][8], cb[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ca[t][j] = t < p.nterms ? cs[(t * 2) * C + c0 + j] : 0.f;
+            cb[t][j] = t < p.nterms ? cs[(t * 2 + 1) * C + c0 + j] : 0.f;
+        }
+    const bool two = p.nterms == 2;
+    const bool bn0 = p.t[0].src.mode == STL_SRC_BN, bn1 = two && p.t[1].src.mode == STL_SRC_BN;
+    const bool r0 = p.t[0].src.relu, r1 = two && p.t[1].src.relu;
+    const void* x0 = p.t[0].src.x;
+    const void* x1 = two ? p.t[1].src.x : p.t[0].src.x;
+    auto term = [&](float* f, const float* a, const float* b, bool bn, bool relu) __attribute__((always_inline)) {
+        if (bn) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float u = fmaf(a[j], f[j], b[j]);
+                f[j] = relu ? fmaxf(u, 0.f) : u;
+            }
+        }
+    };
+    for (uint32_t v = v0; v < total; v += 2 * nthr) {
+        const uint32_t w = v + nthr;
+        const bool hw = w < total;
+        float fa[8], fb[8], ga[8], gb[8];
+        load8<T>(x0, (size_t)v * 8, fa);
+        if (two) load8<T>(x1, (size_t)v * 8, fb);
+        if (hw) {
+            load8<T>(x0, (size_t)w * 8, ga);
+            if (two) load8<T>(x1, (size_t)w * 8, gb);
+        }
+        float s[8];
+        term(fa, ca[0], cb[0], bn0, r0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = 0.f + fa[j];
+        if (two) {
+            term(fb, ca[1], cb[1], bn1, r1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += fb[j];
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] = fmaxf(s[j], 0.f);
+        }
+        store8<T>(p.out, (size_t)v * 8, s);
+        if (hw) {
+            term(ga, ca[0], cb[0], bn0, r0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] = 0.f + ga[j];
+            if (two) {
+                term(gb, ca[1], cb[1], bn1, r1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += gb[j];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] = fmaxf(s[j], 0.f);
+            }
+            store8<T>(p.out, (size_t)w * 8, s);
+        }
     }
 }
 
@@ -441,18 +447,14 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const void* x, const floa
         }
 #pragma unroll
         for (int j = 0; j < J; ++j) sd[j * SDP + tid] = d[j];
-        // the pixel's Ci <= 64 activations: all (up to eight) vectors requested up front (a run-time loop "load, use" pays one memory
-        // round trip per vector; static indices keep the array in registers)
-        float fx[8][8];
-#pragma unroll
-        for (int v8 = 0; v8 < 8; ++v8) load8<TY>(x, (pi < P ? pi * Ci : 0) + (v8 * 8 < Ci ? v8 * 8 : 0), fx[v8]);
-#pragma unroll
-        for (int v8 = 0; v8 < 8; ++v8) {
-            const int c0 = v8 * 8;
-            if (c0 >= Ci) break;
+        for (int c0 = 0; c0 < Ci; c0 += 8) {   // (all of a pixel's vectors up front, round 5: 214 registers + 38 AGPRs, 42 -> 56 us: not kept)
             float f[8], gx[8];
+            if (pi < P) {
+                load8<TY>(x, pi * Ci + c0, f);
+            } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) f[q] = pi < P ? fx[v8][q] : 0.f;
+                for (int q = 0; q < 8; ++q) f[q] = 0.f;
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 sx[tid * (Ci + 1) + c0 + q] = f[q];
@@ -1130,12 +1132,22 @@ extern "C" int stl_fuse_forward(const stl_fuse* pp, void* stream) {
     STL_CHECK(total * 8 < (1ull << 31), "fuse: tensors of 2^31 or more elements are not supported");
     const size_t lds = (size_t)p.nterms * 2 * p.C * 4;
     const dim3 grid(nblocks_for(total, 256, 2048));
+    bool flat = p.nterms <= 2;
+    for (int t = 0; t < p.nterms; ++t) flat = flat && p.t[t].shift == 0;
+    // large one- / two-term sums of the output's resolution: the register-resident form (see fuse_flat_big_kernel)
+    const bool big = flat && total >= ((size_t)1 << 21) && ((size_t)grid.x * 256) % (size_t)(p.C / 8) == 0;
+#define STL_FUSE(TT)                                                                   \
+    do {                                                                               \
+        if (big) STL_LAUNCH(fuse_flat_big_kernel<TT>, grid, dim3(256), lds, ST, p);    \
+        else STL_LAUNCH(fuse_fwd_kernel<TT>, grid, dim3(256), lds, ST, p);             \
+    } while (0)
     if (p.dtype == STL_BF16)
-        STL_LAUNCH(fuse_fwd_kernel<__bf16>, grid, dim3(256), lds, ST, p);
+        STL_FUSE(__bf16);
     else if (p.dtype == STL_F16)
-        STL_LAUNCH(fuse_fwd_kernel<f16>, grid, dim3(256), lds, ST, p);
+        STL_FUSE(f16);
     else
-        STL_LAUNCH(fuse_fwd_kernel<float>, grid, dim3(256), lds, ST, p);
+        STL_FUSE(float);
+#undef STL_FUSE
     STL_LAUNCH_CHECK("fuse_forward");
     return 0;
 }

@@ -551,8 +551,7 @@ def test_fuse_forward_backward_upsample(dt):
 @pytest.mark.parametrize("Cc,nterms,ngrads,nbn", [(32, 1, 1, 0), (32, 2, 3, 1), (64, 2, 4, 3), (48, 2, 2, 2), (256, 2, 1, 1), (32, 4, 2, 1)])
 def test_elementwise_sums_every_operand_count(dt, Cc, nterms, ngrads, nbn):
     """Round 5 rewrote the sum kernels so that every operand of an element is requested up front (absent operands alias operand
-    0): the one- / two-term residual form of stl_fuse_forward (register-resident constants; C = 48 is NOT a divisor of the grid's
-    thread count and takes the general form), the general form with upsampled terms, stl_fuse_backward with 1 .. 4 gradient
+    0): stl_fuse_forward with one to four terms (upsampled ones among them), stl_fuse_backward with 1 .. 4 gradient
     contributions and 0 .. 3 BatchNorm inputs, stl_upsample_backward for shifts 1 .. 3 -- each against plain torch."""
     code, td, tol = DT[dt]
     B, H, W = 2, 16, 24
@@ -631,6 +630,36 @@ def test_elementwise_sums_every_operand_count(dt, Cc, nterms, ngrads, nbn):
         dtf = dtl.float().view(-1, Cc).double()
         got = r2.view(capi.NSHARD, 2, Cc).sum(0)
         assert relerr(got[0], dtf.sum(0)) < tol and relerr(got[1], (dtf * (yf - mean) * rstd).sum(0)) < tol * 3
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_fuse_forward_large_two_term_sum(dt):
+    """>= 2^21 vectors, two terms of the output's resolution: fuse_flat_big_kernel (register-resident BatchNorm constants, two vectors
+    per thread in flight) -- against torch AND bit for bit against fuse_fwd_kernel (a channel count that does not divide the grid's
+    thread count cannot take the big kernel, so the same data is run once more as a narrower tensor through the small one)."""
+    code, td, tol = DT[dt]
+    B, H, W, Cc = 8, 128, 128, 128
+    g = torch.Generator(device="cuda").manual_seed(11)
+    y = nhwc(torch.randn(B, Cc, H, W, device="cuda", generator=g) * 2 + 0.5, td)
+    x = nhwc(torch.randn(B, Cc, H, W, device="cuda", generator=g), td)
+    ga, be = torch.rand(Cc, device="cuda", generator=g) + 0.5, torch.rand(Cc, device="cuda", generator=g) - 0.5
+    st = stats_of(y, Cc)
+
+    def run(b):
+        p = capi.Fuse()
+        p.dtype, p.B, p.H, p.W, p.C, p.nterms, p.relu = code, b, H, W, Cc, 2, 1
+        p.t[0].src = bn_src(y, st, ga, be, B * H * W, False)
+        p.t[1].src.x, p.t[1].src.mode = x.data_ptr(), capi.SRC_PLAIN
+        out = torch.empty(b * H * W * Cc, device="cuda", dtype=td)
+        p.out = out.data_ptr()
+        capi.call("stl_fuse_forward", C.byref(p), stream())
+        torch.cuda.synchronize()
+        return out
+    big = run(B)          # 8 * 128 * 128 * 16 = 2^21 vectors: the big kernel
+    small = run(1)        # the first image alone: 2^18 vectors, the general kernel (same statistics, same constants)
+    assert torch.equal(big[: H * W * Cc], small)
+    ref = F.relu(F.batch_norm(y.float().permute(0, 3, 1, 2), None, None, ga, be, True, 0.1, EPS) + x.float().permute(0, 3, 1, 2))
+    assert relerr(from_nhwc(big, B, H, W, Cc), ref) < tol
 
 
 def test_head_mse_argmax_golden(golden_dir):
