@@ -19,7 +19,7 @@ t0 = win[0]['s']
 def short(n):
     m = re.search(r'conv_core_kernelI(\w+?)Li(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)', n)
     if m: return f"conv<k{m.group(2)},WM{m.group(3)}xWN{m.group(4)},MT{m.group(5)},nva{m.group(7)},q{m.group(8)}>"
-    for k in ('wgrad64', 'wgrad', 'conv_ws', 'conv1x1', 'conv_r2', 'conv_core', 'fuse_bwd', 'fuse_fwd', 'upsample_bwd', 'reduce_slabs', 'weight_prep', 'adam', 'head_bwd', 'head_fwd', 'patch', 'mse', 'bn_running', 'bn_param'):
+    for k in ('wgrad64', 'wgrad', 'conv_ws', 'conv1x1', 'conv_r2', 'conv_core', 'fuse_bwd', 'fuse_fwd', 'fuse_flat_big', 'upsample_bwd', 'reduce_slabs', 'weight_prep', 'adam', 'head_bwd', 'head_fwd', 'patch', 'mse', 'bn_running', 'bn_param'):
         if k in n: return k
     return n[:40]
 ev = []

@@ -9,7 +9,7 @@ usage: python tools/step_traffic.py <fetch_dir> <write_dir> [out.txt]
 import collections, csv, glob, os, re, sys
 
 FAMS = [("wgrad64", "wgrad"), ("wgrad_kernel", "wgrad"), ("conv1x1", "conv1x1"), ("conv_ws", "conv_ws"), ("conv_r2", "conv_r2"), ("conv_core", "conv_core"),
-        ("fuse_fwd", "fuse_fwd"), ("fuse_bwd", "fuse_bwd"), ("upsample_bwd", "upsample"), ("reduce_slabs", "reduce_slabs"),
+        ("fuse_fwd", "fuse_fwd"), ("fuse_flat_big", "fuse_fwd"), ("fuse_bwd", "fuse_bwd"), ("upsample_bwd", "upsample"), ("reduce_slabs", "reduce_slabs"),
         ("weight_prep", "weight_prep"), ("adam", "adam"), ("head_", "head"), ("patch", "patch"), ("mse", "mse")]
 
 

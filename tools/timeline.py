@@ -27,7 +27,7 @@ print(f"step window: {len(win)} kernels, wall {(t1 - t0) / 1e6:.3f} ms, sum of k
 def short(n):
     m = re.search(r'conv_core_kernelI(\w+?)Li(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)', n)
     if m: return f"conv<k{m.group(2)},WM{m.group(3)}xWN{m.group(4)},MT{m.group(5)},NT{m.group(6)},nva{m.group(7)},q{m.group(8)}>"
-    for k in ('wgrad64', 'wgrad', 'conv_ws', 'conv1x1', 'conv_r2', 'conv_core', 'fuse_bwd', 'fuse_fwd', 'upsample_bwd', 'reduce_slabs', 'weight_prep', 'adam', 'head_bwd', 'head_fwd', 'patch', 'mse', 'copyBuffer', 'FillFunctor', 'bn_running', 'bn_param', 'bwd3x3', 'bn_final'):
+    for k in ('wgrad64', 'wgrad', 'conv_ws', 'conv1x1', 'conv_r2', 'conv_core', 'fuse_bwd', 'fuse_fwd', 'fuse_flat_big', 'upsample_bwd', 'reduce_slabs', 'weight_prep', 'adam', 'head_bwd', 'head_fwd', 'patch', 'mse', 'copyBuffer', 'FillFunctor', 'bn_running', 'bn_param', 'bwd3x3', 'bn_final'):
         if k in n: return k
     return n[:40]
 # events
