@@ -22,7 +22,7 @@ rows.sort(key=lambda r: r['s'])
 adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['n']]
 win = rows[adam[-2] + 1:adam[-1] + 1]; t0 = win[0]['s']
 hb = [i for i, r in enumerate(win) if 'head_bwd' in r['n']][0]
-bw = [r for r in win[hb:] if 'adam' not in r['n'] and 'inc_step' not in r['n']]
+bw = [r for r in win[hb:] if 'adam' not in r['n'] and 'inc_step' not in r['n'] and 'sum_partials' not in r['n']]   # (the loss scalar's sum is enqueued behind backward since round 5)
 perq = collections.defaultdict(list)
 for r in bw: perq[r['q']].append(r)
 pers = collections.defaultdict(list)
